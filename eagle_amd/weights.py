@@ -1,0 +1,277 @@
+"""Weight containers for the two networks on the hot path.
+
+No trained weights exist for this build (reference ``.gitignore:164-168`` excludes them and there is no
+network), so every run uses *seeded synthetic* weights.  This module
+
+* enumerates the parameter tensors of HRNet-W48 + head exactly as the reference's ``KeypointModel(57)``
+  names them (``eagle/models/keypoint_hrnet.py:315-351,549-562``; checked by loading the synthetic
+  state-dict into the reference module with ``strict=True`` in ``tests/golden/make_golden.py``), and of
+  YOLOv8-{n,m,l} as ultralytics 8.3.184 names them (``model.N...``; topology pinned by the
+  published parameter counts);
+* generates every tensor from ``numpy.random.Generator(PCG64(hash(seed, tensor name)))`` so a tensor's
+  values depend only on (seed, name, shape, role) -- identical here and on the GPU box;
+* streams a state-dict into a C-ABI handle (``eagle_load_weights`` / ``eagle_finalize_weights``).
+
+The gains below keep activations O(1) through the 293 convolutions (fp16-safe) and give heat-maps /
+class scores with a realistic dynamic range (ultralytics' default class bias would give zero
+detections, the reference's ``init_weights`` std=0.001 collapses every heat-map to 0.5).
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+HRNET_PREFIX = "unnormalized_model.0."
+HEAD_PREFIX = "unnormalized_model.1."
+HRNET_BN_EPS = 1e-5
+YOLO_BN_EPS = 1e-3
+
+YOLO_SCALES = {  # depth, width, max_channels  (ultralytics yolov8.yaml)
+    "n": (0.33, 0.25, 1024),
+    "s": (0.33, 0.50, 1024),
+    "m": (0.67, 0.75, 768),
+    "l": (1.00, 1.00, 512),
+    "x": (1.00, 1.25, 512),
+}
+YOLO_NC = 5
+YOLO_REG_MAX = 16
+
+
+# ----------------------------------------------------------------------------------------------------------
+# parameter enumeration
+# ----------------------------------------------------------------------------------------------------------
+class ConvSpec:
+    """One convolution (+ optional BatchNorm) of a network: ``name`` is the conv module path."""
+
+    __slots__ = ("name", "bn", "cin", "cout", "k", "stride", "role", "bias")
+
+    def __init__(self, name, bn, cin, cout, k, stride, role, bias=False):
+        self.name, self.bn, self.cin, self.cout, self.k, self.stride = name, bn, cin, cout, k, stride
+        self.role, self.bias = role, bias
+
+
+def hrnet_convs():
+    """All conv+bn pairs of KeypointModel(57) in module order (keypoint_hrnet.py:323-351, 505-532)."""
+    P = HRNET_PREFIX
+    L = []
+    L.append(ConvSpec(P + "conv1", P + "bn1", 3, 64, 3, 2, "relu"))
+    L.append(ConvSpec(P + "conv2", P + "bn2", 64, 64, 3, 2, "relu"))
+    inp = 64
+    for b in range(4):  # layer1: 4 Bottlenecks, planes 64, expansion 4
+        q = f"{P}layer1.{b}."
+        L.append(ConvSpec(q + "conv1", q + "bn1", inp, 64, 1, 1, "relu"))
+        L.append(ConvSpec(q + "conv2", q + "bn2", 64, 64, 3, 1, "relu"))
+        L.append(ConvSpec(q + "conv3", q + "bn3", 64, 256, 1, 1, "res_last"))
+        if b == 0:
+            L.append(ConvSpec(q + "downsample.0", q + "downsample.1", 64, 256, 1, 1, "linear"))
+        inp = 256
+    chans = (48, 96, 192, 384)
+    L.append(ConvSpec(P + "transition1.0.0", P + "transition1.0.1", 256, 48, 3, 1, "relu"))
+    L.append(ConvSpec(P + "transition1.1.0.0", P + "transition1.1.0.1", 256, 96, 3, 2, "relu"))
+
+    def stage(idx, n_modules, nb, last_single):
+        for m in range(n_modules):
+            q = f"{P}stage{idx}.{m}."
+            for b in range(nb):
+                for k in range(4):
+                    r = f"{q}branches.{b}.{k}."
+                    L.append(ConvSpec(r + "conv1", r + "bn1", chans[b], chans[b], 3, 1, "relu"))
+                    L.append(ConvSpec(r + "conv2", r + "bn2", chans[b], chans[b], 3, 1, "res_last"))
+            n_out = 1 if (last_single and m == n_modules - 1) else nb
+            for i in range(n_out):
+                for j in range(nb):
+                    r = f"{q}fuse_layers.{i}.{j}."
+                    if j > i:
+                        L.append(ConvSpec(r + "0", r + "1", chans[j], chans[i], 1, 1, "fuse"))
+                    elif j < i:
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            co = chans[i] if last else chans[j]
+                            L.append(ConvSpec(f"{r}{k}.0", f"{r}{k}.1", chans[j], co, 3, 2, "fuse" if last else "relu"))
+
+    stage(2, 1, 2, False)
+    L.append(ConvSpec(P + "transition2.2.0.0", P + "transition2.2.0.1", 96, 192, 3, 2, "relu"))
+    stage(3, 4, 3, False)
+    L.append(ConvSpec(P + "transition3.3.0.0", P + "transition3.3.0.1", 192, 384, 3, 2, "relu"))
+    stage(4, 3, 4, True)
+    L.append(ConvSpec("unnormalized_model.1", None, 48, 57, 3, 1, "heat", bias=True))
+    return L
+
+
+def yolo_channels(variant):
+    d, w, mc = YOLO_SCALES[variant]
+
+    def ch(c):
+        return int(math.ceil(min(c, mc) * w / 8) * 8)
+
+    def rep(n):
+        return max(round(n * d), 1)
+
+    return dict(c=[ch(64), ch(128), ch(256), ch(512), ch(1024)], n=[rep(3), rep(6), rep(6), rep(3)])
+
+
+def yolo_convs(variant="n", nc=YOLO_NC):
+    """All convs of YOLOv8-<variant> detect, ultralytics module names."""
+    cc = yolo_channels(variant)
+    c1, c2, c3, c4, c5 = cc["c"]
+    n1, n2, n3, n4 = cc["n"]
+    L = []
+
+    def conv(i, cin, cout, k, s):
+        L.append(ConvSpec(f"model.{i}.conv", f"model.{i}.bn", cin, cout, k, s, "silu"))
+
+    def sub(name, cin, cout, k, s=1, role="silu"):
+        L.append(ConvSpec(name + ".conv", name + ".bn", cin, cout, k, s, role))
+
+    def c2f(i, cin, cout, n):
+        c = cout // 2
+        sub(f"model.{i}.cv1", cin, 2 * c, 1)
+        sub(f"model.{i}.cv2", (2 + n) * c, cout, 1)
+        for k in range(n):
+            sub(f"model.{i}.m.{k}.cv1", c, c, 3)
+            sub(f"model.{i}.m.{k}.cv2", c, c, 3, role="silu_res")
+
+    conv(0, 3, c1, 3, 2)
+    conv(1, c1, c2, 3, 2)
+    c2f(2, c2, c2, n1)
+    conv(3, c2, c3, 3, 2)
+    c2f(4, c3, c3, n2)
+    conv(5, c3, c4, 3, 2)
+    c2f(6, c4, c4, n3)
+    conv(7, c4, c5, 3, 2)
+    c2f(8, c5, c5, n4)
+    sub("model.9.cv1", c5, c5 // 2, 1)
+    sub("model.9.cv2", c5 * 2, c5, 1)
+    c2f(12, c5 + c4, c4, n1)
+    c2f(15, c4 + c3, c3, n1)
+    conv(16, c3, c3, 3, 2)
+    c2f(18, c3 + c4, c4, n1)
+    conv(19, c4, c4, 3, 2)
+    c2f(21, c4 + c5, c5, n1)
+    hc = (c3, c4, c5)
+    cb = max(16, hc[0] // 4, YOLO_REG_MAX * 4)
+    ck = max(hc[0], min(nc, 100))
+    for l, x in enumerate(hc):
+        sub(f"model.22.cv2.{l}.0", x, cb, 3)
+        sub(f"model.22.cv2.{l}.1", cb, cb, 3)
+        L.append(ConvSpec(f"model.22.cv2.{l}.2", None, cb, 4 * YOLO_REG_MAX, 1, 1, "dfl", bias=True))
+    for l, x in enumerate(hc):
+        sub(f"model.22.cv3.{l}.0", x, ck, 3)
+        sub(f"model.22.cv3.{l}.1", ck, ck, 3)
+        L.append(ConvSpec(f"model.22.cv3.{l}.2", None, ck, nc, 1, 1, "cls", bias=True))
+    return L
+
+
+def param_count(convs, extra=0):
+    n = extra
+    for c in convs:
+        n += c.cout * c.cin * c.k * c.k
+        if c.bn:
+            n += 2 * c.cout
+        if c.bias:
+            n += c.cout
+    return n
+
+
+# ----------------------------------------------------------------------------------------------------------
+# synthetic generation
+# ----------------------------------------------------------------------------------------------------------
+def _rng(seed, name):
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return np.random.Generator(np.random.PCG64(int.from_bytes(h[:8], "little")))
+
+
+# role -> (weight gain on He std, bn gamma centre)
+_ROLE = {
+    "relu": (1.0, 1.0),
+    "silu": (1.1, 1.0),
+    "silu_res": (1.1, 0.5),
+    "res_last": (1.0, 0.15),
+    "linear": (0.7, 1.0),
+    "fuse": (0.7, 0.2),
+}
+
+
+def _gen_conv(seed, c, sd, cls_bias):
+    fan_in = c.cin * c.k * c.k
+    g = _rng(seed, c.name + ".weight")
+    if c.role in _ROLE:
+        wg, gam = _ROLE[c.role]
+        w = g.standard_normal((c.cout, c.cin, c.k, c.k), dtype=np.float32) * np.float32(wg * math.sqrt(2.0 / fan_in))
+        sd[c.name + ".weight"] = w
+        r = _rng(seed, c.bn)
+        sd[c.bn + ".weight"] = (gam * r.uniform(0.8, 1.2, c.cout)).astype(np.float32)
+        sd[c.bn + ".bias"] = (0.15 * r.standard_normal(c.cout)).astype(np.float32)
+        sd[c.bn + ".running_mean"] = (0.15 * r.standard_normal(c.cout)).astype(np.float32)
+        sd[c.bn + ".running_var"] = r.uniform(0.7, 1.3, c.cout).astype(np.float32)
+        sd[c.bn + ".num_batches_tracked"] = np.array(1000, dtype=np.int64)
+        return
+    if c.role == "heat":      # 57 logits: wide enough that sigmoid maxima spread over (0.3, 1)
+        w = g.standard_normal((c.cout, c.cin, c.k, c.k), dtype=np.float32) * np.float32(0.3 * math.sqrt(1.0 / fan_in))
+        b = (-2.0 + 1.5 * g.standard_normal(c.cout)).astype(np.float32)
+    elif c.role == "dfl":     # 4 x 16 bin logits
+        w = g.standard_normal((c.cout, c.cin, c.k, c.k), dtype=np.float32) * np.float32(8.0 * math.sqrt(1.0 / fan_in))
+        b = (0.5 * g.standard_normal(c.cout)).astype(np.float32)
+        # favour small/medium boxes: bias the low bins up
+        b += np.tile(np.linspace(3.0, -3.0, YOLO_REG_MAX), c.cout // YOLO_REG_MAX).astype(np.float32)
+    elif c.role == "cls":     # class logits; bias tuned for a few dozen candidates above 0.15 per frame
+        w = g.standard_normal((c.cout, c.cin, c.k, c.k), dtype=np.float32) * np.float32(24.0 * math.sqrt(1.0 / fan_in))
+        b = (cls_bias + 0.3 * g.standard_normal(c.cout)).astype(np.float32)
+    else:
+        raise ValueError(c.role)
+    sd[c.name + ".weight"] = w
+    sd[c.name + ".bias"] = b
+
+
+def make_hrnet_state_dict(seed=0):
+    """Synthetic state-dict for the reference's ``KeypointModel(57)`` (1754 keys, 63,619,593 parameters)."""
+    sd = OrderedDict()
+    for c in hrnet_convs():
+        _gen_conv(seed, c, sd, 0.0)
+    return sd
+
+
+# Class-head biases [level][class] chosen offline by tests/golden/calibrate_cls_bias.py so that a synthetic
+# frame gives a few dozen candidates above the 0.15 floor; other (variant, seed) pairs use cls_bias.
+CLS_BIAS_TABLE = {
+    ("n", 0): [[-0.9421, -8.6099, 1.4466, -3.2987, -5.3539], [-7.2405, -8.2726, -12.5152, -11.3682, -2.6111], [-3.4973, -3.9737, -8.9049, -5.5132, -5.9112]],
+}
+
+
+def make_yolo_state_dict(variant="n", seed=0, nc=YOLO_NC, cls_bias=-4.5, table=True):
+    """Synthetic ultralytics-style state-dict for YOLOv8-<variant> (nc=5; class map coordinate_model.py:61)."""
+    sd = OrderedDict()
+    for c in yolo_convs(variant, nc):
+        _gen_conv(seed, c, sd, cls_bias)
+    if table and (variant, seed) in CLS_BIAS_TABLE and nc == YOLO_NC:
+        for l, row in enumerate(CLS_BIAS_TABLE[(variant, seed)]):
+            sd[f"model.22.cv3.{l}.2.bias"] = np.asarray(row, np.float32)
+    sd["model.22.dfl.conv.weight"] = np.arange(YOLO_REG_MAX, dtype=np.float32).reshape(1, YOLO_REG_MAX, 1, 1)
+    return sd
+
+
+def n_params(sd):
+    return int(sum(v.size for k, v in sd.items() if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# streaming into a C-ABI handle
+# ----------------------------------------------------------------------------------------------------------
+def load_into(handle, state_dicts):
+    """Feed every float tensor of the given state-dict(s) to ``eagle_load_weights`` and finalize.
+
+    ``handle`` is an :class:`eagle_amd.lib.Handle`.  torch tensors are accepted too (a real checkpoint read
+    with ``torch.load``): they are converted with ``.detach().cpu().numpy()`` -- torch is used for reading
+    weights only."""
+    for sd in state_dicts:
+        for name, t in sd.items():
+            if hasattr(t, "detach"):
+                t = t.detach().cpu().numpy()
+            t = np.asarray(t)
+            if t.dtype.kind != "f":
+                continue
+            handle.load_weight(name, np.ascontiguousarray(t, dtype=np.float32))
+    handle.finalize_weights()

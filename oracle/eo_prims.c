@@ -1,0 +1,589 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under eagle_amd/ may include, link or call this file.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * CPU restatement (plain C, fp32/fp64) of the arithmetic on the reference's per-frame path.  The reference
+ * gets this arithmetic from torch / cv2 / ultralytics; every function cites the call site it
+ * restates.  Parity status:
+ *   - conv / BN / ReLU / bilinear / sigmoid / argmax: pinned against the reference's own HRNet module
+ *     (eagle/models/keypoint_hrnet.py imported in the build container, tests/golden/make_golden.py).
+ *   - resize / letterbox / fitLine / findHomography / perspectiveTransform / YOLOv8 decode / NMS:
+ *     PARITY UNPINNED — cv2, ultralytics and torchvision are absent from /root/reference and from this
+ *     image; restated from their published algorithms and checked against independent
+ *     float64 numpy solvers and brute-force known answers only.
+ *
+ * Numeric contract shared with the HIP kernels (so that integer outputs can be compared bit-for-bit):
+ *   - a convolution output is ONE fp32 fmaf chain:  acc = 0; for c16 in Cin/16-chunks: for (ky,kx): for c in
+ *     chunk: acc = fmaf(x, w, acc);  then v = acc + bias.  (Zero-padded taps contribute fmaf(0,w,acc)=acc.)
+ *     This is the order gfx950's v_mfma_f32_16x16x4_f32 accumulates in (k-ordered fmaf chain, exact fp32).
+ *   - exp() is eo_expf below (pure fp32 fmaf polynomial), never libm, on both sides.
+ *   - built with -ffp-contract=off: every fused multiply-add is an explicit fmaf().
+ *   - "f16" mode emulates fp16 STORAGE (tensors/weights rounded to binary16 RNE, fp32 accumulate); the
+ *     fp16 MFMA's internal summation order is not reproducible, so f16 results are compared by tolerance.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <immintrin.h>
+
+#define EO_ACT_NONE 0
+#define EO_ACT_RELU 1
+#define EO_ACT_SILU 2
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* deterministic fp32 exp / sigmoid / silu                                                               */
+/* ---------------------------------------------------------------------------------------------------- */
+static inline float eo_expf(float x)
+{
+    if (x > 88.0f) x = 88.0f;
+    if (x < -87.0f) x = -87.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);          /* ln2 hi (exact in 11 bits) */
+    r = fmaf(n, -1.42860682030941723e-6f, r);           /* ln2 lo */
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    p = fmaf(p, r2, r);
+    p = p + 1.0f;
+    union { uint32_t u; float f; } s;
+    s.u = (uint32_t)((int)n + 127) << 23;
+    return p * s.f;
+}
+static inline float eo_sigmoidf(float x) { return 1.0f / (1.0f + eo_expf(-x)); }
+static inline float eo_act(float v, int act)
+{
+    if (act == EO_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == EO_ACT_SILU) return v * eo_sigmoidf(v);
+    return v;
+}
+static inline float eo_q16(float v) { return _cvtsh_ss(_cvtss_sh(v, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC)); }
+
+void eo_exp_array(const float* x, float* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = eo_expf(x[i]); }
+void eo_sigmoid_array(const float* x, float* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = eo_sigmoidf(x[i]); }
+void eo_round_f16_array(const float* x, float* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = eo_q16(x[i]); }
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* convolution, NHWC, folded BN.  restates nn.Conv2d+BatchNorm2d(eval)+act (+residuals):                   */
+/*   keypoint_hrnet.py:65-137 (BasicBlock/Bottleneck), :215-278 (fuse), :353-391 (transition); ultralytics */
+/*   Conv / Bottleneck.                                                                  */
+/* x [N,H,W,Cin]  w [KS,KS,Cin,Cout]  bias [Cout]  y [N,Ho,Wo,Cout]; r1/r2 optional [N,Ho,Wo,Cout].        */
+/* v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); optional fp16 rounding of the store.   */
+/* ---------------------------------------------------------------------------------------------------- */
+void eo_conv2d_nhwc(const float* x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                    int KS, int stride, int pad, int Ho, int Wo, float* y, int pre_act, const float* r1,
+                    const float* r2, int post_act, int f16_out)
+{
+    const int CH = 16;
+    #pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < Ho; ++oy) {
+            float* acc = (float*)aligned_alloc(64, sizeof(float) * (size_t)((Cout + 15) & ~15) * 4);
+            for (int ox0 = 0; ox0 < Wo; ox0 += 4) {
+                const int nx = (Wo - ox0) < 4 ? (Wo - ox0) : 4;
+                for (int i = 0; i < nx * Cout; ++i) acc[i] = 0.0f;
+                for (int c0 = 0; c0 < Cin; c0 += CH) {
+                    const int c1 = (c0 + CH < Cin) ? c0 + CH : Cin;
+                    for (int ky = 0; ky < KS; ++ky) {
+                        const int iy = oy * stride + ky - pad;
+                        if (iy < 0 || iy >= H) continue;
+                        for (int kx = 0; kx < KS; ++kx) {
+                            const float* wt = w + ((size_t)(ky * KS + kx) * Cin) * Cout;
+                            for (int px = 0; px < nx; ++px) {
+                                const int ix = (ox0 + px) * stride + kx - pad;
+                                if (ix < 0 || ix >= W) continue;
+                                const float* xp = x + (((size_t)n * H + iy) * W + ix) * Cin;
+                                float* a = acc + (size_t)px * Cout;
+                                for (int c = c0; c < c1; ++c) {
+                                    const float xv = xp[c];
+                                    const float* wr = wt + (size_t)c * Cout;
+                                    #pragma omp simd
+                                    for (int co = 0; co < Cout; ++co) a[co] = fmaf(xv, wr[co], a[co]);
+                                }
+                            }
+                        }
+                    }
+                }
+                for (int px = 0; px < nx; ++px) {
+                    const size_t o = (((size_t)n * Ho + oy) * Wo + ox0 + px) * Cout;
+                    const float* a = acc + (size_t)px * Cout;
+                    for (int co = 0; co < Cout; ++co) {
+                        float v = a[co] + bias[co];
+                        v = eo_act(v, pre_act);
+                        if (r1) v = r1[o + co] + v;
+                        if (r2) v = v + r2[o + co];
+                        v = eo_act(v, post_act);
+                        y[o + co] = f16_out ? eo_q16(v) : v;
+                    }
+                }
+            }
+            free(acc);
+        }
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* bilinear upsample, align_corners=True  (F.interpolate, keypoint_hrnet.py:299-304).  x [N,h,w,C] -> y   */
+/* ---------------------------------------------------------------------------------------------------- */
+void eo_upsample_bilinear_ac(const float* x, int N, int h, int w, int C, int H, int W, float* y)
+{
+    const float sh = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.0f;
+    const float sw = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.0f;
+    #pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int oy = 0; oy < H; ++oy) {
+            const float fy = sh * (float)oy;
+            const int y0 = (int)fy;
+            const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+            for (int ox = 0; ox < W; ++ox) {
+                const float fx = sw * (float)ox;
+                const int x0 = (int)fx;
+                const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+                const float* p00 = x + (((size_t)n * h + y0) * w + x0) * C;
+                const float* p01 = x + (((size_t)n * h + y0) * w + x1) * C;
+                const float* p10 = x + (((size_t)n * h + y1) * w + x0) * C;
+                const float* p11 = x + (((size_t)n * h + y1) * w + x1) * C;
+                float* o = y + (((size_t)n * H + oy) * W + ox) * C;
+                for (int c = 0; c < C; ++c) {
+                    const float top = fmaf(lx1, p01[c], lx0 * p00[c]);
+                    const float bot = fmaf(lx1, p11[c], lx0 * p10[c]);
+                    o[c] = fmaf(ly1, bot, ly0 * top);
+                }
+            }
+        }
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* per-channel first-occurrence argmax of sigmoid(logits): KeypointModel.get_keypoints                    */
+/* (keypoint_hrnet.py:581-593: np.argmax over the sigmoid heat-map, row-major, first maximum).            */
+/* logits [HW, Cs] (NHWC, channel stride Cs), C real channels.                                            */
+/* ---------------------------------------------------------------------------------------------------- */
+void eo_heatmap_argmax(const float* logits, int HW, int Cs, int C, int32_t* idx, float* score)
+{
+    for (int c = 0; c < C; ++c) {
+        float best = -1.0f; int bi = 0;
+        for (int p = 0; p < HW; ++p) {
+            const float s = eo_sigmoidf(logits[(size_t)p * Cs + c]);
+            if (s > best) { best = s; bi = p; }
+        }
+        idx[c] = bi; score[c] = best;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* u8 bilinear resize (cv2.resize INTER_LINEAR as used by A.Resize(540,960), coordinate_model.py:62-64,   */
+/* and by ultralytics LetterBox).  PARITY UNPINNED (cv2 absent).                    */
+/*  - exact 2x decimation takes cv2's INTER_AREA fast path: (a+b+c+d+2)>>2                                 */
+/*  - otherwise half-pixel centres, 11-bit coefficients, cv2's 8u vertical pass rounding.                  */
+/* src [sh,sw,3] (row stride in bytes), dst [dh,dw,3] dense.                                               */
+/* ---------------------------------------------------------------------------------------------------- */
+static void eo_lin_coef(int dsize, int ssize, int* ofs, short* co)
+{
+    const double scale = (double)ssize / dsize;
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= ssize - 1) { s = ssize - 1; f = 0.f; }
+        ofs[d] = s;
+        co[2 * d] = (short)lrintf((1.f - f) * 2048.f);
+        co[2 * d + 1] = (short)lrintf(f * 2048.f);
+    }
+}
+void eo_resize_linear_u8c3(const uint8_t* src, int sh, int sw, int64_t sstride, uint8_t* dst, int dh, int dw)
+{
+    if (sh == dh && sw == dw) {
+        for (int y = 0; y < dh; ++y) memcpy(dst + (size_t)y * dw * 3, src + (size_t)y * sstride, (size_t)dw * 3);
+        return;
+    }
+    if (sh == 2 * dh && sw == 2 * dw) {
+        for (int y = 0; y < dh; ++y)
+            for (int x = 0; x < dw; ++x)
+                for (int c = 0; c < 3; ++c) {
+                    const uint8_t* p = src + (size_t)(2 * y) * sstride + (size_t)(2 * x) * 3 + c;
+                    dst[((size_t)y * dw + x) * 3 + c] = (uint8_t)((p[0] + p[3] + p[sstride] + p[sstride + 3] + 2) >> 2);
+                }
+        return;
+    }
+    int* xo = (int*)malloc(sizeof(int) * dw); short* xc = (short*)malloc(sizeof(short) * 2 * dw);
+    int* yo = (int*)malloc(sizeof(int) * dh); short* yc = (short*)malloc(sizeof(short) * 2 * dh);
+    eo_lin_coef(dw, sw, xo, xc);
+    eo_lin_coef(dh, sh, yo, yc);
+    for (int y = 0; y < dh; ++y) {
+        const int y0 = yo[y], y1 = (y0 + 1 < sh) ? y0 + 1 : y0;
+        const int b0 = yc[2 * y], b1 = yc[2 * y + 1];
+        for (int x = 0; x < dw; ++x) {
+            const int x0 = xo[x], x1 = (x0 + 1 < sw) ? x0 + 1 : x0;
+            const int a0 = xc[2 * x], a1 = xc[2 * x + 1];
+            for (int c = 0; c < 3; ++c) {
+                const int t0 = src[(size_t)y0 * sstride + x0 * 3 + c] * a0 + src[(size_t)y0 * sstride + x1 * 3 + c] * a1;
+                const int t1 = src[(size_t)y1 * sstride + x0 * 3 + c] * a0 + src[(size_t)y1 * sstride + x1 * 3 + c] * a1;
+                dst[((size_t)y * dw + x) * 3 + c] = (uint8_t)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+    free(xo); free(xc); free(yo); free(yc);
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* YOLOv8 Detect decode for one level (ultralytics Detect inference path):               */
+/* box [A,64] DFL logits, cls [A,>=nc] logits (NHWC), anchors = cell centres, stride s.                    */
+/* out rows [A, 4+nc] = (cx,cy,w,h)*stride, sigmoid(cls).                                                  */
+/* ---------------------------------------------------------------------------------------------------- */
+void eo_yolo_decode_level(const float* box, int box_cs, const float* cls, int cls_cs, int nc, int gh, int gw,
+                          float stride, float* out)
+{
+    for (int a = 0; a < gh * gw; ++a) {
+        const float ax = (float)(a % gw) + 0.5f, ay = (float)(a / gw) + 0.5f;
+        float d[4];
+        for (int s = 0; s < 4; ++s) {
+            const float* l = box + (size_t)a * box_cs + s * 16;
+            float m = l[0];
+            for (int i = 1; i < 16; ++i) m = l[i] > m ? l[i] : m;
+            float e[16], den = 0.f;
+            for (int i = 0; i < 16; ++i) { e[i] = eo_expf(l[i] - m); den = den + e[i]; }
+            float num = 0.f;
+            for (int i = 0; i < 16; ++i) num = fmaf((float)i, e[i] / den, num);
+            d[s] = num;
+        }
+        const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+        float* o = out + (size_t)a * (4 + nc);
+        o[0] = ((x1 + x2) / 2.0f) * stride;
+        o[1] = ((y1 + y2) / 2.0f) * stride;
+        o[2] = (x2 - x1) * stride;
+        o[3] = (y2 - y1) * stride;
+        for (int c = 0; c < nc; ++c) o[4 + c] = eo_sigmoidf(cls[(size_t)a * cls_cs + c]);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* cv2.fitLine(pts, DIST_L2, 0, 0.01, 0.01) closed form (coordinate_model.py:106).        */
+/* PARITY UNPINNED.  pts float32 [n,2] -> (vx,vy,x0,y0) float32.                                          */
+/* ---------------------------------------------------------------------------------------------------- */
+void eo_fit_line_l2(const float* pts, int n, float* line)
+{
+    double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0;
+    for (int i = 0; i < n; ++i) {
+        const double px = pts[2 * i], py = pts[2 * i + 1];
+        x += px; y += py; x2 += px * px; y2 += py * py; xy += px * py;
+    }
+    const double w = (double)n;
+    x /= w; y /= w; x2 /= w; y2 /= w; xy /= w;
+    const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
+    const float t = (float)atan2(2 * dxy, dx2 - dy2) / 2;
+    line[0] = (float)cos(t); line[1] = (float)sin(t);
+    line[2] = (float)x; line[3] = (float)y;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* cv2.findHomography(src, dst, RANSAC, 5.0) (coordinate_model.py:355). PARITY UNPINNED. */
+/* ---------------------------------------------------------------------------------------------------- */
+/* symmetric 9x9 eigen-solve by cyclic Jacobi in float64; returns eigenvector of the smallest eigenvalue. */
+static void eo_jacobi9_smallest(double A[9][9], double v[9])
+{
+    double V[9][9];
+    for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 8; ++p) for (int q = p + 1; q < 9; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 9; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int i = 1; i < 9; ++i) if (A[i][i] < A[m][m]) m = i;
+    for (int k = 0; k < 9; ++k) v[k] = V[k][m];
+}
+
+/* normalised DLT ("runKernel"): src/dst double [n][2]; H[9]; returns 1 on success */
+int eo_dlt_homography(const double* src, const double* dst, const int* sel, int n, double* H)
+{
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        cM[0] += src[2 * k]; cM[1] += src[2 * k + 1]; cm[0] += dst[2 * k]; cm[1] += dst[2 * k + 1];
+    }
+    cM[0] /= n; cM[1] /= n; cm[0] /= n; cm[1] /= n;
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        sM[0] += fabs(src[2 * k] - cM[0]); sM[1] += fabs(src[2 * k + 1] - cM[1]);
+        sm[0] += fabs(dst[2 * k] - cm[0]); sm[1] += fabs(dst[2 * k + 1] - cm[1]);
+    }
+    if (fabs(sM[0]) < 2.220446049250313e-16 || fabs(sM[1]) < 2.220446049250313e-16 ||
+        fabs(sm[0]) < 2.220446049250313e-16 || fabs(sm[1]) < 2.220446049250313e-16) return 0;
+    sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
+    double LtL[9][9];
+    memset(LtL, 0, sizeof(LtL));
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        const double X = (src[2 * k] - cM[0]) * sM[0], Y = (src[2 * k + 1] - cM[1]) * sM[1];
+        const double x = (dst[2 * k] - cm[0]) * sm[0], y = (dst[2 * k + 1] - cm[1]) * sm[1];
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int a = 0; a < 9; ++a) for (int b = a; b < 9; ++b) LtL[a][b] += Lx[a] * Lx[b] + Ly[a] * Ly[b];
+    }
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < a; ++b) LtL[a][b] = LtL[b][a];
+    double h[9];
+    eo_jacobi9_smallest(LtL, h);
+    /* H = inv(T_dst) * H0 * T_src,  T = [[s0,0,-c0*s0],[0,s1,-c1*s1],[0,0,1]] */
+    const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double t[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += iT[3 * r + k] * h[3 * k + c]; t[3 * r + c] = s; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += t[3 * r + k] * T[3 * k + c]; H[3 * r + c] = s; }
+    if (fabs(H[8]) < 2.220446049250313e-16) return 0;
+    const double inv = 1.0 / H[8];
+    for (int k = 0; k < 9; ++k) H[k] *= inv;
+    H[8] = 1.0;
+    return 1;
+}
+
+/* squared reprojection error in dst units, float like cv2's computeError */
+static void eo_reproj_err(const double* src, const double* dst, int n, const double* H, float* err)
+{
+    for (int i = 0; i < n; ++i) {
+        const double X = src[2 * i], Y = src[2 * i + 1];
+        const double ww = 1.0 / (H[6] * X + H[7] * Y + 1.0);
+        const double dx = (H[0] * X + H[1] * Y + H[2]) * ww - dst[2 * i];
+        const double dy = (H[3] * X + H[4] * Y + H[5]) * ww - dst[2 * i + 1];
+        err[i] = (float)(dx * dx + dy * dy);
+    }
+}
+
+/* cv2 "checkSubset" for 4 points: no 3 collinear in either set + consistent orientation */
+static int eo_collinear_last(const double* p, const int* idx, int count)
+{
+    const int i = count - 1;
+    for (int j = 0; j < i; ++j) {
+        const double dx1 = p[2 * idx[j]] - p[2 * idx[i]], dy1 = p[2 * idx[j] + 1] - p[2 * idx[i] + 1];
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = p[2 * idx[k]] - p[2 * idx[i]], dy2 = p[2 * idx[k] + 1] - p[2 * idx[i] + 1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
+                return 1;
+        }
+    }
+    return 0;
+}
+static int eo_check_subset4(const double* src, const double* dst, const int* idx)
+{
+    for (int c = 3; c <= 4; ++c)
+        if (eo_collinear_last(src, idx, c) || eo_collinear_last(dst, idx, c)) return 0;
+    static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int a = idx[tt[i][0]], b = idx[tt[i][1]], c = idx[tt[i][2]];
+        const double A = src[2 * a] * (src[2 * b + 1] - src[2 * c + 1]) - src[2 * a + 1] * (src[2 * b] - src[2 * c]) +
+                         (src[2 * b] * src[2 * c + 1] - src[2 * c] * src[2 * b + 1]);
+        const double B = dst[2 * a] * (dst[2 * b + 1] - dst[2 * c + 1]) - dst[2 * a + 1] * (dst[2 * b] - dst[2 * c]) +
+                         (dst[2 * b] * dst[2 * c + 1] - dst[2 * c] * dst[2 * b + 1]);
+        negative += (A * B < 0);
+    }
+    return negative == 0 || negative == 4;
+}
+
+static uint32_t eo_rng_next(uint64_t* st)
+{
+    *st = (uint64_t)(uint32_t)(*st) * 4164903690ULL + (uint32_t)(*st >> 32);
+    return (uint32_t)(*st);
+}
+
+static int eo_ransac_update_iters(double p, double ep, int model_points, int max_iters)
+{
+    if (p < 0) p = 0; if (p > 1) p = 1;
+    if (ep < 0) ep = 0; if (ep > 1) ep = 1;
+    const double num0 = 1.0 - p;
+    const double num = num0 > 2.2250738585072014e-308 ? num0 : 2.2250738585072014e-308;
+    const double denom = 1.0 - pow(1.0 - ep, model_points);
+    if (denom < 2.2250738585072014e-308) return 0;
+    const double ln = log(num), ld = log(denom);
+    return (ld >= 0 || -ln >= max_iters * (-ld)) ? max_iters : (int)lrint(ln / ld);
+}
+
+/* Levenberg-Marquardt polish of the 8 free entries (h33 = 1), at most 10 iterations, residual =
+ * reprojection error in dst units (cv2 HomographyRefineCallback + LMSolver). */
+static void eo_lm_residual(const double* src, const double* dst, int n, const double* h, double* r, double* J)
+{
+    for (int i = 0; i < n; ++i) {
+        const double Mx = src[2 * i], My = src[2 * i + 1];
+        double ww = h[6] * Mx + h[7] * My + 1.0;
+        ww = fabs(ww) > 2.220446049250313e-16 ? 1.0 / ww : 0.0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        r[2 * i] = xi - dst[2 * i]; r[2 * i + 1] = yi - dst[2 * i + 1];
+        if (J) {
+            double* a = J + (size_t)(2 * i) * 8; double* b = a + 8;
+            a[0] = Mx * ww; a[1] = My * ww; a[2] = ww; a[3] = a[4] = a[5] = 0.0;
+            a[6] = -Mx * ww * xi; a[7] = -My * ww * xi;
+            b[0] = b[1] = b[2] = 0.0; b[3] = Mx * ww; b[4] = My * ww; b[5] = ww;
+            b[6] = -Mx * ww * yi; b[7] = -My * ww * yi;
+        }
+    }
+}
+static int eo_solve8(double A[8][8], double b[8], double x[8])
+{   /* Gaussian elimination with partial pivoting */
+    double M[8][9];
+    for (int i = 0; i < 8; ++i) { for (int j = 0; j < 8; ++j) M[i][j] = A[i][j]; M[i][8] = b[i]; }
+    for (int c = 0; c < 8; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 8; ++r) if (fabs(M[r][c]) > fabs(M[p][c])) p = r;
+        if (fabs(M[p][c]) < 1e-300) return 0;
+        if (p != c) for (int j = 0; j < 9; ++j) { const double t = M[c][j]; M[c][j] = M[p][j]; M[p][j] = t; }
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = M[r][c] / M[c][c];
+            for (int j = c; j < 9; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 7; i >= 0; --i) {
+        double s = M[i][8];
+        for (int j = i + 1; j < 8; ++j) s -= M[i][j] * x[j];
+        x[i] = s / M[i][i];
+    }
+    return 1;
+}
+static const double EO_P10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5,
+                                   1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10,
+                                   1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
+void eo_lm_refine(const double* src, const double* dst, int n, double* H, int max_iters)
+{
+    double* r = (double*)malloc(sizeof(double) * 2 * n);
+    double* rn = (double*)malloc(sizeof(double) * 2 * n);
+    double* J = (double*)malloc(sizeof(double) * 2 * n * 8);
+    double h[8]; for (int k = 0; k < 8; ++k) h[k] = H[k];
+    eo_lm_residual(src, dst, n, h, r, J);
+    double S = 0; for (int i = 0; i < 2 * n; ++i) S += r[i] * r[i];
+    int lambdaLg10 = -3;
+    for (int it = 0; it < max_iters; ++it) {
+        double A[8][8], g[8];
+        for (int a = 0; a < 8; ++a) {
+            g[a] = 0; for (int i = 0; i < 2 * n; ++i) g[a] += J[(size_t)i * 8 + a] * r[i];
+            for (int b = 0; b < 8; ++b) { double s = 0; for (int i = 0; i < 2 * n; ++i) s += J[(size_t)i * 8 + a] * J[(size_t)i * 8 + b]; A[a][b] = s; }
+        }
+        int improved = 0;
+        for (int tries = 0; tries < 16 && !improved; ++tries) {
+            double Ap[8][8], d[8], hn[8], gm[8];
+            const double lam = EO_P10[lambdaLg10 + 16];
+            for (int a = 0; a < 8; ++a) { for (int b = 0; b < 8; ++b) Ap[a][b] = A[a][b]; Ap[a][a] += lam * A[a][a]; gm[a] = -g[a]; }
+            if (!eo_solve8(Ap, gm, d)) { lambdaLg10 = lambdaLg10 + 1 > 16 ? 16 : lambdaLg10 + 1; continue; }
+            for (int k = 0; k < 8; ++k) hn[k] = h[k] + d[k];
+            eo_lm_residual(src, dst, n, hn, rn, 0);
+            double Sn = 0; for (int i = 0; i < 2 * n; ++i) Sn += rn[i] * rn[i];
+            if (Sn < S) {
+                for (int k = 0; k < 8; ++k) h[k] = hn[k];
+                S = Sn; improved = 1;
+                lambdaLg10 = lambdaLg10 - 1 < -16 ? -16 : lambdaLg10 - 1;
+            } else {
+                lambdaLg10 = lambdaLg10 + 1 > 16 ? 16 : lambdaLg10 + 1;
+            }
+        }
+        if (!improved) break;
+        eo_lm_residual(src, dst, n, h, r, J);
+    }
+    for (int k = 0; k < 8; ++k) H[k] = h[k];
+    H[8] = 1.0;
+    free(r); free(rn); free(J);
+}
+
+/* src (image) / dst (world) float32 [n,2]; returns 1 and fills H[9] (double), mask[n] on success. */
+int eo_find_homography_ransac(const float* srcf, const float* dstf, int n, double thresh, int max_iters,
+                              double confidence, int refine_iters, double* H, uint8_t* mask)
+{
+    if (n < 4) return 0;
+    double* src = (double*)malloc(sizeof(double) * 2 * n);
+    double* dst = (double*)malloc(sizeof(double) * 2 * n);
+    float* err = (float*)malloc(sizeof(float) * n);
+    uint8_t* m = (uint8_t*)malloc(n);
+    for (int i = 0; i < 2 * n; ++i) { src[i] = srcf[i]; dst[i] = dstf[i]; }
+    int ok = 0;
+    double best[9];
+    if (n == 4) {
+        ok = eo_dlt_homography(src, dst, 0, 4, best);
+        for (int i = 0; i < n; ++i) mask[i] = 1;
+    } else {
+        uint64_t rng = 0xffffffffffffffffULL;
+        int niters = max_iters, max_good = 0;
+        const float t2 = (float)(thresh * thresh);
+        for (int iter = 0; iter < niters; ++iter) {
+            int idx[4], found = 0;
+            for (int attempt = 0; attempt < 1000 && !found; ++attempt) {
+                for (int i = 0; i < 4; ++i) {
+                    int v, dup;
+                    do {
+                        v = (int)(eo_rng_next(&rng) % (uint32_t)n);
+                        dup = 0;
+                        for (int j = 0; j < i; ++j) dup |= (idx[j] == v);
+                    } while (dup);
+                    idx[i] = v;
+                }
+                found = eo_check_subset4(src, dst, idx);
+            }
+            if (!found) { if (iter == 0) { ok = 0; goto done; } break; }
+            double Hc[9];
+            if (!eo_dlt_homography(src, dst, idx, 4, Hc)) continue;
+            eo_reproj_err(src, dst, n, Hc, err);
+            int good = 0;
+            for (int i = 0; i < n; ++i) { m[i] = err[i] <= t2; good += m[i]; }
+            if (good > (max_good > 3 ? max_good : 3)) {
+                memcpy(mask, m, n); memcpy(best, Hc, sizeof(best));
+                max_good = good;
+                niters = eo_ransac_update_iters(confidence, (double)(n - good) / n, 4, niters);
+            }
+        }
+        ok = max_good > 0;
+        if (ok) {
+            /* compress to inliers, DLT on all of them, then LM polish */
+            int* sel = (int*)malloc(sizeof(int) * n); int ni = 0;
+            for (int i = 0; i < n; ++i) if (mask[i]) sel[ni++] = i;
+            double* s2 = (double*)malloc(sizeof(double) * 2 * ni); double* d2 = (double*)malloc(sizeof(double) * 2 * ni);
+            for (int i = 0; i < ni; ++i) { s2[2 * i] = src[2 * sel[i]]; s2[2 * i + 1] = src[2 * sel[i] + 1]; d2[2 * i] = dst[2 * sel[i]]; d2[2 * i + 1] = dst[2 * sel[i] + 1]; }
+            double Hr[9];
+            if (eo_dlt_homography(s2, d2, 0, ni, Hr)) {
+                memcpy(best, Hr, sizeof(best));
+                if (refine_iters > 0) eo_lm_refine(s2, d2, ni, best, refine_iters);
+            }
+            free(sel); free(s2); free(d2);
+        }
+    }
+done:
+    if (ok) memcpy(H, best, sizeof(best));
+    free(src); free(dst); free(err); free(m);
+    return ok;
+}
+
+/* cv2.perspectiveTransform (coordinate_model.py:383,400-403): double compute, float store */
+void eo_perspective_transform(const float* pts, int n, const double* H, float* out)
+{
+    for (int i = 0; i < n; ++i) {
+        const double x = pts[2 * i], y = pts[2 * i + 1];
+        double w = H[6] * x + H[7] * y + H[8];
+        if (fabs(w) > 2.220446049250313e-16) {
+            w = 1.0 / w;
+            out[2 * i] = (float)((H[0] * x + H[1] * y + H[2]) * w);
+            out[2 * i + 1] = (float)((H[3] * x + H[4] * y + H[5]) * w);
+        } else {
+            out[2 * i] = out[2 * i + 1] = 0.f;
+        }
+    }
+}

@@ -1,0 +1,150 @@
+"""ctypes bindings of oracle/eo_prims.c  (ORACLE — test infrastructure only; see eo_prims.c header)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libeagle_oracle.so")
+
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "eo_prims.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def conv2d(x, w, b, stride=1, pad=None, pre=ACT_NONE, r1=None, r2=None, post=ACT_NONE, f16_out=False):
+    """x [N,H,W,Cin], w [KS,KS,Cin,Cout] (BN folded), b [Cout] -> [N,Ho,Wo,Cout]"""
+    x = _f32(x); w = _f32(w); b = _f32(b)
+    N, H, W, Cin = x.shape
+    KS, _, Cin2, Cout = w.shape
+    assert Cin == Cin2, (x.shape, w.shape)
+    if pad is None:
+        pad = KS // 2
+    Ho = (H + 2 * pad - KS) // stride + 1
+    Wo = (W + 2 * pad - KS) // stride + 1
+    y = np.empty((N, Ho, Wo, Cout), np.float32)
+    if r1 is not None:
+        r1 = _f32(r1); assert r1.shape == y.shape
+    if r2 is not None:
+        r2 = _f32(r2); assert r2.shape == y.shape
+    lib().eo_conv2d_nhwc(_p(x), N, H, W, Cin, _p(w), _p(b), Cout, KS, stride, pad, Ho, Wo, _p(y), pre,
+                         _p(r1), _p(r2), post, int(f16_out))
+    return y
+
+
+def upsample_bilinear_ac(x, H, W):
+    x = _f32(x)
+    N, h, w, Cc = x.shape
+    y = np.empty((N, H, W, Cc), np.float32)
+    lib().eo_upsample_bilinear_ac(_p(x), N, h, w, Cc, H, W, _p(y))
+    return y
+
+
+def sigmoid(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().eo_sigmoid_array(_p(x), _p(y), C.c_int64(x.size))
+    return y
+
+
+def expf(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().eo_exp_array(_p(x), _p(y), C.c_int64(x.size))
+    return y
+
+
+def round_f16(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().eo_round_f16_array(_p(x), _p(y), C.c_int64(x.size))
+    return y
+
+
+def heatmap_argmax(logits, n_real):
+    """logits [H,W,Cs] -> (idx int32[n_real] flat row-major, score float32[n_real])"""
+    logits = _f32(logits)
+    H, W, Cs = logits.shape
+    idx = np.empty(n_real, np.int32)
+    sc = np.empty(n_real, np.float32)
+    lib().eo_heatmap_argmax(_p(logits), H * W, Cs, n_real, _p(idx, C.c_int32), _p(sc))
+    return idx, sc
+
+
+def resize_linear_u8c3(src, dh, dw):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw, c = src.shape
+    assert c == 3
+    dst = np.empty((dh, dw, 3), np.uint8)
+    lib().eo_resize_linear_u8c3(_p(src, C.c_uint8), sh, sw, C.c_int64(sw * 3), _p(dst, C.c_uint8), dh, dw)
+    return dst
+
+
+def yolo_decode_level(box, cls, nc, stride):
+    """box [gh,gw,>=64] logits, cls [gh,gw,>=nc] logits -> [gh*gw, 4+nc]"""
+    box = _f32(box); cls = _f32(cls)
+    gh, gw, bcs = box.shape
+    out = np.empty((gh * gw, 4 + nc), np.float32)
+    lib().eo_yolo_decode_level(_p(box), bcs, _p(cls), cls.shape[2], nc, gh, gw, C.c_float(stride), _p(out))
+    return out
+
+
+def fit_line_l2(pts):
+    pts = _f32(pts).reshape(-1, 2)
+    line = np.empty(4, np.float32)
+    lib().eo_fit_line_l2(_p(pts), pts.shape[0], _p(line))
+    return line
+
+
+def dlt_homography(src, dst):
+    src = np.ascontiguousarray(src, np.float64).reshape(-1, 2)
+    dst = np.ascontiguousarray(dst, np.float64).reshape(-1, 2)
+    H = np.empty(9, np.float64)
+    ok = lib().eo_dlt_homography(_p(src, C.c_double), _p(dst, C.c_double), None, src.shape[0], _p(H, C.c_double))
+    return H.reshape(3, 3) if ok else None
+
+
+def find_homography_ransac(src, dst, thresh=5.0, max_iters=2000, confidence=0.995, refine_iters=10):
+    """cv2.findHomography(src, dst, cv2.RANSAC, thresh) restatement -> (H float64 3x3 | None, mask u8 [n] | None)"""
+    src = _f32(src).reshape(-1, 2)
+    dst = _f32(dst).reshape(-1, 2)
+    n = src.shape[0]
+    H = np.empty(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ok = lib().eo_find_homography_ransac(_p(src), _p(dst), n, C.c_double(thresh), max_iters, C.c_double(confidence),
+                                         refine_iters, _p(H, C.c_double), _p(mask, C.c_uint8))
+    if not ok:
+        return None, None
+    return H.reshape(3, 3), mask[:n]
+
+
+def perspective_transform(pts, H):
+    pts = _f32(pts).reshape(-1, 2)
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    out = np.empty_like(pts)
+    lib().eo_perspective_transform(_p(pts), pts.shape[0], _p(H, C.c_double), _p(out))
+    return out

@@ -1,0 +1,60 @@
+"""Drop-in for the hot path of the reference's ``CoordinateModel`` (eagle/models/coordinate_model.py:47-628) in the
+stateless configuration: every per-frame number comes from the HIP library through the C ABI.
+
+Same constructor keywords and method names as the reference: ``CoordinateModel(keypoint_conf=0.3, detector_conf=0.35)``,
+``get_coordinates(frames, fps, ...)`` -> ``{i: {"Coordinates", "Time", "Keypoints", "Boundaries"}}`` (cm.py:415),
+``detect_objects(frame)``, ``detect_keypoints(frame)``.  The stateful modes of the reference (tracker IDs, LK-flow
+cadence, calibration) are SURVEY §8f "next" rows: asking for them raises instead of silently degrading."""
+import numpy as np
+
+from . import lib, records, weights
+from .pitch import INTERSECTION_TO_PITCH_POINTS
+
+
+class CoordinateModel:
+    def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
+                 detector="n", det_imgsz=640, batch=8, precision="f16", device=0, hrnet_state_dict=None,
+                 detector_state_dict=None, seed=0, use_graph=False):
+        self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
+        self.batch = batch
+        self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
+                                 det_imgsz=det_imgsz, batch=batch,
+                                 precision=lib.PREC_F16 if precision == "f16" else lib.PREC_F32,
+                                 keypoint_conf=keypoint_conf, detector_conf=detector_conf,
+                                 detector_floor=min(detector_conf, 0.15), use_graph=int(use_graph))
+        # the reference reads eagle/models/weights/*.pt|.pth (cm.py:55-59); none exist here -> seeded synthetic
+        hs = hrnet_state_dict if hrnet_state_dict is not None else weights.make_hrnet_state_dict(seed)
+        ys = detector_state_dict if detector_state_dict is not None else weights.make_yolo_state_dict(detector, seed)
+        weights.load_into(self.handle, [hs, ys])
+
+    # ---- raw records ---------------------------------------------------------------------------------
+    def process_records(self, frames):
+        return self.handle.process(np.asarray(frames))
+
+    # ---- reference-shaped API ------------------------------------------------------------------------
+    def get_coordinates(self, frames, fps: int, num_homography: int = 1, num_keypoint_detection: int = 1,
+                        verbose: bool = True, calibration: bool = False) -> dict:
+        homography_interval = max(1, int(fps / max(1, num_homography)))
+        keypoint_interval = max(1, int(fps / max(1, num_keypoint_detection)))
+        if calibration or homography_interval != 1 or keypoint_interval != 1:
+            raise NotImplementedError("only the stateless cadence (keypoint_interval == homography_interval == 1, "
+                                      "calibration off) is on the GPU path; see DESIGN.md 'out of scope'")
+        recs = self.process_records(frames)
+        return {i: records.to_reference_dict(r, i, fps) for i, r in enumerate(recs)}
+
+    def detect_objects(self, frame):
+        rec = self.process_records(frame[None])[0]
+        res = {"Player": {}, "Goalkeeper": {}}
+        for cname, objs in records._objects(rec).items():
+            for oid, d in objs.items():
+                res.setdefault(cname, {})[oid] = {"BBox": [int(d["bx1"]), int(d["by1"]), int(d["bx2"]), int(d["by2"])],
+                                                  "Confidence": float(d["conf"]),
+                                                  "Bottom_center": [int(d["foot_x"]), int(d["foot_y"])]}
+        if any(int(d["cls"]) == 2 for d in rec["det"][: int(rec["n_det"])]):
+            res.setdefault("Ball", {})
+        return res
+
+    def detect_keypoints(self, frame):
+        rec = self.process_records(frame[None])[0]
+        return {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"]))
+                for k in rec["kp"][: int(rec["n_kp"])] if not k["synthesized"]}

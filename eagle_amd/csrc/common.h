@@ -1,0 +1,104 @@
+// Internal declarations shared by the runtime (graph/weights/api) and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/eagle.h"
+
+namespace eagle {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+struct Err {
+    int code;
+    std::string msg;
+};
+// Thrown inside the library only; every extern "C" entry catches it and converts to a status code.
+[[noreturn]] void fail(int code, const char* fmt, ...);
+
+#define HIP_CHECK(expr)                                                                                \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) ::eagle::fail(EAGLE_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                            __FILE__, __LINE__);                                       \
+    } while (0)
+
+// A view of an NHWC activation: C channels starting at channel `off` of a buffer whose pixel stride is `cs`.
+struct TView {
+    void* p = nullptr;   // device base pointer of the underlying buffer
+    int n = 0, h = 0, w = 0;
+    int c = 0;           // channels of this view (padded to the kernel granularity)
+    int cs = 0;          // channel stride (elements per pixel) of the underlying buffer
+    int off = 0;         // first channel of the view
+    int f32 = 0;         // element type: 0 fp16, 1 fp32
+    size_t esize() const { return f32 ? 4 : 2; }
+    TView slice(int o, int cc) const { TView v = *this; v.off = off + o; v.c = cc; return v; }
+};
+
+// ---- convolution ------------------------------------------------------------------------------------------
+struct ConvConfig {          // tile configuration chosen per layer at graph-build time
+    int ks = 3, stride = 1;
+    int kc = 0;              // input channels staged per LDS chunk
+    int nt = 0;              // 16-wide Cout tiles per workgroup (BN = 16*nt)
+    int wx = 2;              // 16-pixel sub-tiles per tile row; tile = (16/wx) rows x (16*wx) cols, 4 per wave
+    int cin = 0, cout_pad = 0;
+};
+struct ConvLaunch {
+    ConvConfig cfg;
+    TView x, y, r1, r2;      // r1/r2 optional (p == nullptr)
+    const void* w = nullptr; // pre-tiled weights for cfg
+    const float* bias = nullptr;
+    int pre_act = 0, post_act = 0;
+    int out_f32 = 0;         // store fp32 regardless of precision (logits)
+    double flop = 0;         // algorithmic 2*MAC (unpadded)
+};
+// returns false when no kernel instance exists for cfg
+bool conv_supported(int precision, const ConvConfig& cfg);
+void conv_launch(int precision, const ConvLaunch& L, hipStream_t s);
+size_t conv_weight_elems(int precision, const ConvConfig& cfg);
+// w_hwio: folded fp32 weights [ks][ks][cin_real][cout_real]; dst: host buffer of conv_weight_elems elements
+void conv_tile_weights(int precision, const ConvConfig& cfg, const float* w_hwio, int cin_real, int cout_real, void* dst);
+ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo);
+
+// ---- other kernels ----------------------------------------------------------------------------------------
+struct LetterBox { int new_h, new_w, top, left, out_h, out_w; };
+LetterBox letterbox_geometry(int h, int w, int imgsz);
+void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det,
+                       const LetterBox& lb, hipStream_t s);
+struct FuseUp { TView z; };
+void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s);
+void maxpool5_launch(const TView& x, const TView& y, hipStream_t s);
+void upsample2_launch(const TView& x, const TView& y, hipStream_t s);
+
+struct ArgmaxPart { float score; int idx; };
+// logits: fp32 view [n,h,w,64]; parts: [n][chunks][64]
+void heat_argmax_launch(const TView& logits, ArgmaxPart* parts, int chunks, hipStream_t s);
+
+struct DetLevel { TView box, cls; int gh, gw; float stride; int a0; };
+struct DetScratch {           // per-handle device scratch for decode + NMS, sized for `batch` frames
+    int A = 0;                // anchors per frame
+    float* boxes = nullptr;   // [n][A][4] xyxy (net-input pixels)
+    float* conf = nullptr;    // [n][A]
+    int* cls = nullptr;       // [n][A]
+    unsigned long long* keys = nullptr;  // [n][A] candidate sort keys
+    int* count = nullptr;     // [n]
+};
+void yolo_decode_launch(const DetLevel* lv, int n_lv, int n, int nc, float conf_floor, const DetScratch& sc, hipStream_t s);
+
+struct PostParams {
+    int frame_h, frame_w, in_h, in_w;        // frame size, detector input size
+    int hm_h, hm_w, hm_chunks;
+    double keypoint_conf, detector_conf, ransac_thresh;
+    float nms_iou;
+    int ransac_max_iters, lm_iters;
+};
+void nms_launch(const DetScratch& sc, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s);
+void post_launch(const ArgmaxPart* parts, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s);
+void homography_only_launch(const float* d_img, const float* d_world, int npts, double thresh, int max_iters, int lm_iters,
+                            double* d_H, uint8_t* d_mask, int* d_ok, hipStream_t s);
+
+}  // namespace eagle

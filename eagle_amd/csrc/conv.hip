@@ -1,0 +1,407 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4), NHWC, BatchNorm pre-folded, fused epilogue.
+//
+// Replaces nn.Conv2d + BatchNorm2d + ReLU (+ residual) of the reference's HRNet (eagle/models/keypoint_hrnet.py:65-137,
+// 215-278, 353-391, 553-558) and ultralytics' Conv/Bottleneck.
+//
+// GEMM view:  D[Cout x pixels] = W[Cout x K] * X[K x pixels],  K = ks*ks*Cin.
+//   * weights are the MFMA "A" operand, activations the "B" operand, so each lane ends up holding 4 CONSECUTIVE
+//     output channels of one pixel -> 8-byte (fp16) / 16-byte (fp32) NHWC stores and residual loads.
+//   * a workgroup (4 waves) owns a (16/wx) x (16*wx) output-pixel tile and BN = 16*NT output channels; each wave
+//     owns 4 sub-tiles of 16 consecutive pixels.  The input halo tile and the weight slice of one Cin-chunk (KC
+//     channels) are staged in LDS; pixel stride in LDS is padded so ds_read_b128 over 16 pixels is conflict-free.
+//   * fp16 family: v_mfma_f32_16x16x32_f16, K flattened over (tap, 8-channel group); fp32 accumulate.
+//   * fp32 family: v_mfma_f32_16x16x4_f32 in the canonical K order (16-channel chunk, tap, channel): gfx950
+//     accumulates these as a k-ordered fmaf chain, so outputs are bit-identical to oracle/eo_prims.c.
+// Epilogue: v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); store (fp16 RNE / fp32).
+#include "common.h"
+#include "dmath.h"
+
+namespace eagle {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half4 = __attribute__((ext_vector_type(4))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct ConvArgs {
+    const void* x; int xcs, xoff; int N, H, W;
+    const void* w; const float* bias;
+    void* y; int ycs, yoff; int Ho, Wo;
+    const void* r1; int r1cs, r1off;
+    const void* r2; int r2cs, r2off;
+    int pre_act, post_act, out_f32;
+    int wx, tiles_x, tiles_y, nchunks;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// fp16 family
+// ------------------------------------------------------------------------------------------------------------
+template <int KC> struct F16Geom {
+    static constexpr int G = KC / 8;                                   // 16-byte groups per pixel per chunk
+    static constexpr int PS = KC * 2 + ((G % 2 == 0) ? 16 : 0);        // LDS pixel stride (bytes), odd in 16-B units
+};
+
+template <int KS, int S, int KC, int NT>
+__global__ __launch_bounds__(256) void conv_f16_kernel(ConvArgs a)
+{
+    constexpr int G = F16Geom<KC>::G;
+    constexpr int PS = F16Geom<KC>::PS;
+    constexpr int TAPS = KS * KS;
+    constexpr int NGR = TAPS * G;
+    constexpr int NI = (NGR + 3) / 4;
+    constexpr int BN = NT * 16;
+    constexpr int WBYTES = NI * 4 * BN * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_w = smem;
+    char* lds_a = smem + WBYTES;
+
+    const int WX = a.wx, TH = 16 / WX, TW = 16 * WX;
+    const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, lx = lane & 15;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int nb = blockIdx.y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - KS / 2, ix0 = ox0 * S - KS / 2;
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int abase[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+        abase[p] = ((row * S) * halo_w + (xb * 16 + lx) * S) * PS;
+    }
+    int koff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g = 4 * i + q;
+        if (g < NGR) {
+            const int tap = g / G, cg = g - tap * G, ky = tap / KS, kx = tap - ky * KS;
+            koff[i] = (ky * halo_w + kx) * PS + cg * 16;
+        } else {
+            koff[i] = 0;
+        }
+    }
+    const int wlane = (q * BN + lx) * 16;
+    const _Float16* xg = (const _Float16*)a.x;
+    const int ngroups = halo_h * halo_w * G;
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        {   // weights of this (nb, chunk): one contiguous pre-tiled image
+            const char* wsrc = (const char*)a.w + (size_t)(nb * a.nchunks + ch) * WBYTES;
+            for (int o = tid * 16; o < WBYTES; o += 256 * 16) *(uint4*)(lds_w + o) = *(const uint4*)(wsrc + o);
+        }
+        const int c0 = a.xoff + ch * KC;
+        for (int idx = tid; idx < ngroups; idx += 256) {
+            const int pix = idx / G, g = idx - pix * G;
+            const int hy = pix / halo_w, hx = pix - hy * halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *(const uint4*)(xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0 + g * 8);
+            *(uint4*)(lds_a + pix * PS + g * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            half8 wa[NT], xb[4];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) wa[tt] = *(const half8*)(lds_w + wlane + i * (4 * BN * 16) + tt * 256);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) xb[p] = *(const half8*)(lds_a + abase[p] + koff[i]);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds channels co..co+3 of pixel (oy, ox)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+        const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int co = nb * BN + tt * 16 + q * 4;
+            const float4 bv = *(const float4*)(a.bias + co);
+            float v[4] = {acc[tt][p][0] + bv.x, acc[tt][p][1] + bv.y, acc[tt][p][2] + bv.z, acc[tt][p][3] + bv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.pre_act);
+            if (a.r1) {
+                const half4 rv = *(const half4*)((const _Float16*)a.r1 + pidx * a.r1cs + a.r1off + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
+            }
+            if (a.r2) {
+                const half4 rv = *(const half4*)((const _Float16*)a.r2 + pidx * a.r2cs + a.r2off + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] + (float)rv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.post_act);
+            if (a.out_f32) {
+                *(float4*)((float*)a.y + pidx * a.ycs + a.yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *(half4*)((_Float16*)a.y + pidx * a.ycs + a.yoff + co) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 exact family.  KC = 16 (or 4 for the 3-channel stems); canonical K order.
+// ------------------------------------------------------------------------------------------------------------
+template <int KS, int S, int KC, int NT>
+__global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgs a)
+{
+    constexpr int PSF = KC + 1;                 // LDS pixel stride in floats (odd)
+    constexpr int TAPS = KS * KS;
+    constexpr int CSTEPS = KC / 4;
+    constexpr int NI = TAPS * CSTEPS;
+    constexpr int BN = NT * 16;
+    constexpr int WFLOATS = NI * 4 * BN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds_w = (float*)smem;
+    float* lds_a = lds_w + WFLOATS;
+
+    const int WX = a.wx, TH = 16 / WX, TW = 16 * WX;
+    const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, lx = lane & 15;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int nb = blockIdx.y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - KS / 2, ix0 = ox0 * S - KS / 2;
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int abase[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+        abase[p] = ((row * S) * halo_w + (xb * 16 + lx) * S) * PSF + q;
+    }
+    const int wlane = q * BN + lx;
+    const float* xg = (const float*)a.x;
+    const int nelem = halo_h * halo_w * CSTEPS;   // float4 groups
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        {
+            const float* wsrc = (const float*)a.w + (size_t)(nb * a.nchunks + ch) * WFLOATS;
+            for (int o = tid * 4; o < WFLOATS; o += 256 * 4) *(float4*)(lds_w + o) = *(const float4*)(wsrc + o);
+        }
+        const int c0 = a.xoff + ch * KC;
+        for (int idx = tid; idx < nelem; idx += 256) {
+            const int pix = idx / CSTEPS, g = idx - pix * CSTEPS;
+            const int hy = pix / halo_w, hx = pix - hy * halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *(const float4*)(xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0 + g * 4);
+            float* d = lds_a + pix * PSF + g * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const int toff = (ky * halo_w + kx) * PSF;
+#pragma unroll
+            for (int cs = 0; cs < CSTEPS; ++cs) {
+                const int i = tap * CSTEPS + cs;
+                float wa[NT], xb[4];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) wa[tt] = lds_w[wlane + i * (4 * BN) + tt * 16];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) xb[p] = lds_a[abase[p] + toff + cs * 4];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+        const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int co = nb * BN + tt * 16 + q * 4;
+            const float4 bv = *(const float4*)(a.bias + co);
+            float v[4] = {acc[tt][p][0] + bv.x, acc[tt][p][1] + bv.y, acc[tt][p][2] + bv.z, acc[tt][p][3] + bv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.pre_act);
+            if (a.r1) {
+                const float4 rv = *(const float4*)((const float*)a.r1 + pidx * a.r1cs + a.r1off + co);
+                v[0] = rv.x + v[0]; v[1] = rv.y + v[1]; v[2] = rv.z + v[2]; v[3] = rv.w + v[3];
+            }
+            if (a.r2) {
+                const float4 rv = *(const float4*)((const float*)a.r2 + pidx * a.r2cs + a.r2off + co);
+                v[0] = v[0] + rv.x; v[1] = v[1] + rv.y; v[2] = v[2] + rv.z; v[3] = v[3] + rv.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.post_act);
+            *(float4*)((float*)a.y + pidx * a.ycs + a.yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side: geometry, instance table, weight tiling
+// ------------------------------------------------------------------------------------------------------------
+static int f16_ps(int kc) { const int g = kc / 8; return kc * 2 + ((g % 2 == 0) ? 16 : 0); }
+static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
+
+static size_t lds_bytes(int precision, const ConvConfig& c)
+{
+    const int th = 16 / c.wx, tw = 16 * c.wx;
+    const int hw = (tw - 1) * c.stride + c.ks, hh = (th - 1) * c.stride + c.ks;
+    const int bn = c.nt * 16;
+    if (precision == EAGLE_PREC_F16) return (size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)hh * hw * f16_ps(c.kc);
+    return (size_t)c.ks * c.ks * (c.kc / 4) * 4 * bn * 4 + (size_t)hh * hw * (c.kc + 1) * 4;
+}
+
+typedef void (*ConvKernel)(ConvArgs);
+struct Inst { int prec, ks, s, kc, nt; ConvKernel fn; };
+
+#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, conv_f16_kernel<KS, S, KC, NT>}
+#define I32(KS, S, KC, NT) {EAGLE_PREC_F32, KS, S, KC, NT, conv_f32_kernel<KS, S, KC, NT>}
+#define ALLNT16(KS, S, KC) I16(KS, S, KC, 1), I16(KS, S, KC, 2), I16(KS, S, KC, 3), I16(KS, S, KC, 4), I16(KS, S, KC, 6)
+#define ALLNT32(KS, S, KC) I32(KS, S, KC, 1), I32(KS, S, KC, 2), I32(KS, S, KC, 3), I32(KS, S, KC, 4), I32(KS, S, KC, 6)
+static const Inst g_inst[] = {
+    // 3x3 stride 1
+    ALLNT16(3, 1, 16), ALLNT16(3, 1, 32), ALLNT16(3, 1, 48), ALLNT16(3, 1, 64),
+    // 3x3 stride 2 (halo is 4x larger: small chunks)
+    ALLNT16(3, 2, 8), ALLNT16(3, 2, 16),
+    // 1x1
+    ALLNT16(1, 1, 16), ALLNT16(1, 1, 32), ALLNT16(1, 1, 48), ALLNT16(1, 1, 64),
+    // exact fp32 family
+    ALLNT32(3, 1, 16), ALLNT32(3, 2, 16), ALLNT32(3, 2, 4), ALLNT32(1, 1, 16),
+};
+
+static const Inst* find_inst(int precision, const ConvConfig& c)
+{
+    for (const Inst& i : g_inst)
+        if (i.prec == precision && i.ks == c.ks && i.s == c.stride && i.kc == c.kc && i.nt == c.nt) return &i;
+    return nullptr;
+}
+bool conv_supported(int precision, const ConvConfig& c) { return find_inst(precision, c) != nullptr; }
+
+ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo)
+{
+    ConvConfig c;
+    c.ks = ks; c.stride = stride; c.cin = cin_pad; c.cout_pad = cout_pad;
+    static const int nts[] = {6, 4, 3, 2, 1};
+    c.nt = 1;
+    for (int nt : nts)
+        if (cout_pad % (16 * nt) == 0) { c.nt = nt; break; }
+    c.wx = (wo > 16) ? 2 : 1;
+    if (precision == EAGLE_PREC_F32) {
+        c.kc = (cin_pad < 16) ? 4 : 16;
+        return c;
+    }
+    const int bn = c.nt * 16;
+    static const int kcs[] = {64, 48, 32, 16, 8};
+    c.kc = 8;
+    for (int kc : kcs) {
+        if (cin_pad % kc) continue;
+        if (stride == 2 && kc > 16) continue;
+        if (ks == 3 && kc * bn > 3072) continue;
+        c.kc = kc;
+        break;
+    }
+    return c;
+}
+
+size_t conv_weight_elems(int precision, const ConvConfig& c)
+{
+    const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc;
+    if (precision == EAGLE_PREC_F16) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 4 * bn * 8;
+    return (size_t)nblk * nch * c.ks * c.ks * (c.kc / 4) * 4 * bn;
+}
+
+void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int cin_real, int cout_real, void* dst)
+{
+    const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc, taps = c.ks * c.ks;
+    auto W = [&](int tap, int ci, int co) -> float {
+        return (ci < cin_real && co < cout_real) ? w[((size_t)tap * cin_real + ci) * cout_real + co] : 0.0f;
+    };
+    if (precision == EAGLE_PREC_F16) {
+        const int G = c.kc / 8, NGR = taps * G, NI = f16_ni(c.ks, c.kc);
+        _Float16* d = (_Float16*)dst;
+        for (int b = 0; b < nblk; ++b)
+            for (int ch = 0; ch < nch; ++ch)
+                for (int g = 0; g < NI * 4; ++g)
+                    for (int nn = 0; nn < bn; ++nn)
+                        for (int j = 0; j < 8; ++j) {
+                            float v = 0.f;
+                            if (g < NGR) {
+                                const int tap = g / G, cg = g % G;
+                                v = W(tap, ch * c.kc + cg * 8 + j, b * bn + nn);
+                            }
+                            *d++ = (_Float16)v;
+                        }
+    } else {
+        const int CSTEPS = c.kc / 4;
+        float* d = (float*)dst;
+        for (int b = 0; b < nblk; ++b)
+            for (int ch = 0; ch < nch; ++ch)
+                for (int tap = 0; tap < taps; ++tap)
+                    for (int cs = 0; cs < CSTEPS; ++cs)
+                        for (int qq = 0; qq < 4; ++qq)
+                            for (int nn = 0; nn < bn; ++nn) *d++ = W(tap, ch * c.kc + cs * 4 + qq, b * bn + nn);
+    }
+}
+
+void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
+{
+    const ConvConfig& c = L.cfg;
+    const Inst* inst = find_inst(precision, c);
+    if (!inst) fail(EAGLE_E_NOKERNEL, "no conv kernel instance: prec=%d ks=%d s=%d kc=%d nt=%d", precision, c.ks, c.stride, c.kc, c.nt);
+    ConvArgs a;
+    a.x = L.x.p; a.xcs = L.x.cs; a.xoff = L.x.off; a.N = L.x.n; a.H = L.x.h; a.W = L.x.w;
+    a.w = L.w; a.bias = L.bias;
+    a.y = L.y.p; a.ycs = L.y.cs; a.yoff = L.y.off; a.Ho = L.y.h; a.Wo = L.y.w;
+    a.r1 = L.r1.p; a.r1cs = L.r1.cs; a.r1off = L.r1.off;
+    a.r2 = L.r2.p; a.r2cs = L.r2.cs; a.r2off = L.r2.off;
+    a.pre_act = L.pre_act; a.post_act = L.post_act; a.out_f32 = L.out_f32 || precision == EAGLE_PREC_F32;
+    a.wx = c.wx;
+    const int th = 16 / c.wx, tw = 16 * c.wx;
+    a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
+    a.nchunks = c.cin / c.kc;
+    const size_t lds = lds_bytes(precision, c);
+    static bool attr_done[sizeof(g_inst) / sizeof(g_inst[0])] = {};
+    const size_t ii = inst - g_inst;
+    if (!attr_done[ii]) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)inst->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done[ii] = true;
+    }
+    dim3 grid(a.tiles_x * a.tiles_y * a.N, c.cout_pad / (c.nt * 16));
+    hipLaunchKernelGGL(inst->fn, grid, dim3(256), lds, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace eagle

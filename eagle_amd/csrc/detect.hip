@@ -1,0 +1,196 @@
+// YOLOv8 Detect tail on the GPU: DFL decode + class sigmoid + confidence filter (K6), then per-frame
+// descending-confidence sort, class-offset IoU suppression, scale_boxes and the reference's detection ->
+// object-dict integer rules (K7).  Replaces ultralytics' Detect inference path, ops.non_max_suppression +
+// torchvision.ops.nms + scale_boxes and eagle/models/coordinate_model.py:598-627.
+#include "common.h"
+#include "dmath.h"
+
+namespace eagle {
+
+// ------------------------------------------------------------------------------------------------------------
+// K6: one thread per anchor.
+// ------------------------------------------------------------------------------------------------------------
+struct DecodeArgs { DetLevel lv[3]; int n_lv, n, nc, A; float floor_; DetScratch sc; };
+
+__global__ __launch_bounds__(256) void yolo_decode_kernel(DecodeArgs a)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.n * a.A) return;
+    const int f = gid / a.A, an = gid - f * a.A;
+    int l = 0;
+    while (l + 1 < a.n_lv && an >= a.lv[l + 1].a0) ++l;
+    const DetLevel& L = a.lv[l];
+    const int cell = an - L.a0, gy = cell / L.gw, gx = cell - gy * L.gw;
+    const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+    const float* bp = (const float*)L.box.p + ((size_t)f * L.gh * L.gw + cell) * L.box.cs + L.box.off;
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float lg[16];
+        const float4* q = (const float4*)(bp + s * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float4 v = q[i]; lg[4 * i] = v.x; lg[4 * i + 1] = v.y; lg[4 * i + 2] = v.z; lg[4 * i + 3] = v.w; }
+        float m = lg[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = lg[i] > m ? lg[i] : m;
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { lg[i] = d_expf(lg[i] - m); den = den + lg[i]; }
+        float num = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) num = fmaf((float)i, lg[i] / den, num);
+        d[s] = num;
+    }
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    const float cx = ((x1 + x2) / 2.0f) * L.stride, cy = ((y1 + y2) / 2.0f) * L.stride;
+    const float bw = (x2 - x1) * L.stride, bh = (y2 - y1) * L.stride;
+    const float hw = bw / 2.0f, hh = bh / 2.0f;
+    const float* cp = (const float*)L.cls.p + ((size_t)f * L.gh * L.gw + cell) * L.cls.cs + L.cls.off;
+    float best = -1.f; int bj = 0;
+    for (int c = 0; c < a.nc; ++c) {
+        const float pr = d_sigmoidf(cp[c]);
+        if (pr > best) { best = pr; bj = c; }
+    }
+    const size_t o = (size_t)f * a.A + an;
+    *(float4*)(a.sc.boxes + o * 4) = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+    a.sc.conf[o] = best;
+    a.sc.cls[o] = bj;
+    if (best > a.floor_) {
+        const int pos = atomicAdd(a.sc.count + f, 1);
+        a.sc.keys[(size_t)f * a.A + pos] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)an);
+    }
+}
+
+void yolo_decode_launch(const DetLevel* lv, int n_lv, int n, int nc, float conf_floor, const DetScratch& sc, hipStream_t s)
+{
+    DecodeArgs a;
+    for (int i = 0; i < n_lv; ++i) a.lv[i] = lv[i];
+    a.n_lv = n_lv; a.n = n; a.nc = nc; a.A = sc.A; a.floor_ = conf_floor; a.sc = sc;
+    HIP_CHECK(hipMemsetAsync(sc.count, 0, sizeof(int) * n, s));
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((n * sc.A + 255) / 256), dim3(256), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K7: one workgroup (1024 threads) per frame.
+// ------------------------------------------------------------------------------------------------------------
+#define NMS_T 1024
+struct NmsArgs { DetScratch sc; PostParams pp; EagleFrameResult* out; int cap; };
+
+__global__ __launch_bounds__(NMS_T) void nms_kernel(NmsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = (unsigned long long*)smem;            // cap entries
+    unsigned char* dead = (unsigned char*)(keys + a.cap);            // cap bytes
+    __shared__ int kept[EAGLE_MAX_DET];
+    __shared__ int s_nk;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int A = a.sc.A;
+    const int cnt = min(a.sc.count[f], A);
+    int np2 = 1;
+    while (np2 < cnt) np2 <<= 1;
+    const unsigned long long* gk = a.sc.keys + (size_t)f * A;
+    for (int i = tid; i < np2; i += NMS_T) { keys[i] = i < cnt ? gk[i] : 0ull; dead[i] = 0; }
+    __syncthreads();
+    // bitonic sort, descending
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += NMS_T) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = keys[i], y = keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    const float* boxes = a.sc.boxes + (size_t)f * A * 4;
+    const int* cls = a.sc.cls + (size_t)f * A;
+    if (tid == 0) s_nk = 0;
+    __syncthreads();
+    // greedy suppression in sorted order (torchvision.ops.nms on boxes + cls*7680, IoU > thr suppresses)
+    for (int i = 0; i < cnt; ++i) {
+        if (dead[i]) continue;                                 // uniform: everyone reads the same byte
+        const int nk = s_nk;
+        if (nk >= EAGLE_MAX_DET) break;
+        const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const float offi = (float)cls[ai] * 7680.0f;
+        const float4 bi4 = *(const float4*)(boxes + (size_t)ai * 4);
+        const float bx1 = bi4.x + offi, by1 = bi4.y + offi, bx2 = bi4.z + offi, by2 = bi4.w + offi;
+        const float areai = (bx2 - bx1) * (by2 - by1);
+        for (int j = i + 1 + tid; j < cnt; j += NMS_T) {
+            if (dead[j]) continue;
+            const int aj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
+            const float offj = (float)cls[aj] * 7680.0f;
+            const float4 bj4 = *(const float4*)(boxes + (size_t)aj * 4);
+            const float cx1 = bj4.x + offj, cy1 = bj4.y + offj, cx2 = bj4.z + offj, cy2 = bj4.w + offj;
+            const float areaj = (cx2 - cx1) * (cy2 - cy1);
+            const float xx1 = fmaxf(bx1, cx1), yy1 = fmaxf(by1, cy1), xx2 = fminf(bx2, cx2), yy2 = fminf(by2, cy2);
+            const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+            const float inter = iw * ih;
+            const float ovr = inter / (areai + areaj - inter);
+            if (ovr > a.pp.nms_iou) dead[j] = 1;
+        }
+        __syncthreads();
+        if (tid == 0) { kept[nk] = i; s_nk = nk + 1; }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int K = s_nk;
+    EagleFrameResult* R = a.out + f;
+    if (tid == 0) { R->n_det = K; R->n_candidates = cnt; }
+    // scale_boxes + detection -> object rules (cm.py:598-627)
+    const double gain_d = fmin((double)a.pp.in_h / a.pp.frame_h, (double)a.pp.in_w / a.pp.frame_w);
+    const float gain = (float)gain_d;
+    const float padx = (float)nearbyint((a.pp.in_w - a.pp.frame_w * gain_d) / 2 - 0.1);
+    const float pady = (float)nearbyint((a.pp.in_h - a.pp.frame_h * gain_d) / 2 - 0.1);
+    const float fw = (float)a.pp.frame_w, fh = (float)a.pp.frame_h;
+    for (int k = tid; k < K; k += NMS_T) {
+        const int i = kept[k];
+        const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const float4 b = *(const float4*)(boxes + (size_t)ai * 4);
+        EagleDet d;
+        d.x1 = fminf(fmaxf((b.x - padx) / gain, 0.f), fw);
+        d.y1 = fminf(fmaxf((b.y - pady) / gain, 0.f), fh);
+        d.x2 = fminf(fmaxf((b.z - padx) / gain, 0.f), fw);
+        d.y2 = fminf(fmaxf((b.w - pady) / gain, 0.f), fh);
+        d.conf = __uint_as_float((unsigned)(keys[i] >> 32));
+        d.cls = cls[ai];
+        int ix1 = (int)d.x1, iy1 = (int)d.y1, ix2 = (int)d.x2, iy2 = (int)d.y2;
+        const bool conf_ok = !((double)d.conf < a.pp.detector_conf);
+        d.id = -1; d.reported = 0;
+        if (d.cls == 0 || d.cls == 1) {
+            ix1 = min(max(ix1, 0), a.pp.frame_w - 1); ix2 = min(max(ix2, 0), a.pp.frame_w - 1);
+            iy1 = min(max(iy1, 0), a.pp.frame_h - 1); iy2 = min(max(iy2, 0), a.pp.frame_h - 1);
+            d.id = k; d.reported = conf_ok;
+        } else if (d.cls == 2) {
+            int e = 0;
+            for (int m = 0; m < k; ++m) {
+                const int am = (int)(0xFFFFFFFFu - (unsigned)(keys[kept[m]] & 0xFFFFFFFFull));
+                e += (cls[am] == 2);
+            }
+            d.id = e; d.reported = conf_ok;
+        }
+        d.bx1 = ix1; d.by1 = iy1; d.bx2 = ix2; d.by2 = iy2;
+        d.foot_x = (ix1 + ix2) / 2; d.foot_y = iy2;
+        d.pitch_xf = d.pitch_yf = 0.f; d.pitch_x = d.pitch_y = 0; d.in_bounds = 0; d.pad[0] = d.pad[1] = 0;
+        R->det[k] = d;
+    }
+}
+
+void nms_launch(const DetScratch& sc, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s)
+{
+    NmsArgs a; a.sc = sc; a.pp = pp; a.out = d_out;
+    int cap = 1;
+    while (cap < sc.A) cap <<= 1;
+    a.cap = cap;
+    const size_t lds = (size_t)cap * 9;
+    static bool done = false;
+    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); done = true; }
+    if (lds > 160 * 1024 - 2048) fail(EAGLE_E_INVALID, "too many anchors for the NMS workgroup: %d", sc.A);
+    hipLaunchKernelGGL(nms_kernel, dim3(n), dim3(NMS_T), lds, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace eagle

@@ -1,0 +1,294 @@
+// Bandwidth-bound kernels of the per-frame path: fused frame preprocess (K1), HRNet fuse = bilinear
+// align_corners upsample + N-way sum + ReLU (K4), SPPF max-pool / nearest x2 / concat-by-slice (K8), and the
+// per-channel first-maximum of sigmoid(logits) (K5).  All NHWC, 16-byte vector accesses per lane.
+#include "common.h"
+#include "dmath.h"
+
+namespace eagle {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+
+// ------------------------------------------------------------------------------------------------------------
+// K1: one read of the BGR u8 frame -> (a) 540x960 ImageNet-normalised RGB tensor for HRNet
+//     (cv2.cvtColor + A.Resize + A.Normalize, eagle/models/coordinate_model.py:62-64,489-491) and
+//     (b) letter-boxed RGB/255 tensor for the detector (ultralytics LetterBox).
+// u8 resize restates cv2.resize INTER_LINEAR: 2x decimation = area fast path, else 11-bit fixed point.
+// ------------------------------------------------------------------------------------------------------------
+struct ResizeAxis { int s0, s1; int a0, a1; };
+
+__device__ __forceinline__ ResizeAxis lin_coef(int d, int dsize, int ssize)
+{
+    const double scale = (double)ssize / (double)dsize;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= ssize - 1) { s = ssize - 1; f = 0.f; }
+    ResizeAxis r;
+    r.s0 = s; r.s1 = (s + 1 < ssize) ? s + 1 : s;
+    r.a0 = (int)(short)lrintf((1.f - f) * 2048.f);
+    r.a1 = (int)(short)lrintf(f * 2048.f);
+    return r;
+}
+
+// resized RGB u8 pixel (dy,dx) of an (sh,sw)->(dh,dw) resize; src is BGR
+__device__ __forceinline__ void resize_px(const uint8_t* src, int sh, int sw, int dh, int dw, int dy, int dx, int rgb[3])
+{
+    const size_t rs = (size_t)sw * 3;
+    if (sh == dh && sw == dw) {
+        const uint8_t* p = src + dy * rs + dx * 3;
+        rgb[0] = p[2]; rgb[1] = p[1]; rgb[2] = p[0];
+    } else if (sh == 2 * dh && sw == 2 * dw) {
+        const uint8_t* p = src + (size_t)(2 * dy) * rs + (size_t)(2 * dx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[2 - c] = (p[c] + p[3 + c] + p[rs + c] + p[rs + 3 + c] + 2) >> 2;
+    } else {
+        const ResizeAxis ax = lin_coef(dx, dw, sw), ay = lin_coef(dy, dh, sh);
+        const uint8_t* r0 = src + ay.s0 * rs; const uint8_t* r1 = src + ay.s1 * rs;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int t0 = r0[ax.s0 * 3 + c] * ax.a0 + r0[ax.s1 * 3 + c] * ax.a1;
+            const int t1 = r1[ax.s0 * 3 + c] * ax.a0 + r1[ax.s1 * 3 + c] * ax.a1;
+            rgb[2 - c] = (((ay.a0 * (t0 >> 4)) >> 16) + ((ay.a1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_px(const TView& v, size_t pix, float r, float g, float b)
+{
+    if constexpr (sizeof(T) == 2) {
+        half8 o = {(_Float16)r, (_Float16)g, (_Float16)b, 0, 0, 0, 0, 0};
+        *(half8*)((_Float16*)v.p + pix * v.cs + v.off) = o;
+    } else {
+        *(float4*)((float*)v.p + pix * v.cs + v.off) = make_float4(r, g, b, 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* bgr, int n, int h, int w, TView kp, TView det, LetterBox lb)
+{
+    const size_t fsz = (size_t)h * w * 3;
+    const int kp_px = kp.h * kp.w, det_px = det.h * det.w;
+    const int per = kp_px + det_px;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * per; i += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / per);
+        int r = (int)(i - (size_t)f * per);
+        const uint8_t* src = bgr + f * fsz;
+        int rgb[3];
+        if (r < kp_px) {
+            const int dy = r / kp.w, dx = r - dy * kp.w;
+            resize_px(src, h, w, kp.h, kp.w, dy, dx, rgb);
+            const float m0 = 0x1.eeb334p+6f, m1 = 0x1.d11eb8p+6f, m2 = 0x1.9e1eb8p+6f;      // f32(mean)*255
+            const float s0 = 0x1.18926cp-6f, s1 = 0x1.1ed5bp-6f, s2 = 0x1.1d8f56p-6f;       // 1/(f32(std)*255)
+            store_px<T>(kp, (size_t)f * kp_px + r, ((float)rgb[0] - m0) * s0, ((float)rgb[1] - m1) * s1, ((float)rgb[2] - m2) * s2);
+        } else {
+            r -= kp_px;
+            const int dy = r / det.w, dx = r - dy * det.w;
+            const int yy = dy - lb.top, xx = dx - lb.left;
+            if (yy >= 0 && yy < lb.new_h && xx >= 0 && xx < lb.new_w) resize_px(src, h, w, lb.new_h, lb.new_w, yy, xx, rgb);
+            else rgb[0] = rgb[1] = rgb[2] = 114;
+            store_px<T>(det, (size_t)f * det_px + r, (float)rgb[0] / 255.0f, (float)rgb[1] / 255.0f, (float)rgb[2] / 255.0f);
+        }
+    }
+}
+
+LetterBox letterbox_geometry(int h, int w, int imgsz)
+{
+    // ultralytics LetterBox(new_shape=imgsz, auto=True, stride=32, center=True, scaleup=True)
+    const double r = std::min((double)imgsz / h, (double)imgsz / w);
+    LetterBox lb;
+    lb.new_w = (int)nearbyint(w * r); lb.new_h = (int)nearbyint(h * r);
+    double dw = (imgsz - lb.new_w) % 32, dh = (imgsz - lb.new_h) % 32;
+    dw /= 2; dh /= 2;
+    lb.top = (int)nearbyint(dh - 0.1); lb.left = (int)nearbyint(dw - 0.1);
+    const int bottom = (int)nearbyint(dh + 0.1), right = (int)nearbyint(dw + 0.1);
+    lb.out_h = lb.new_h + lb.top + bottom; lb.out_w = lb.new_w + lb.left + right;
+    return lb;
+}
+
+void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det,
+                       const LetterBox& lb, hipStream_t s)
+{
+    const size_t total = (size_t)n * (kp.h * kp.w + det.h * det.w);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    if (precision == EAGLE_PREC_F16) hipLaunchKernelGGL(preprocess_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb);
+    else hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// vector helpers: VEC channels per thread (8 fp16 / 4 fp32)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<_Float16> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const void* p, size_t e) { half8 h = *(const half8*)((const _Float16*)p + e); for (int i = 0; i < 8; ++i) v[i] = (float)h[i]; }
+    __device__ __forceinline__ void store(void* p, size_t e) const { half8 h; for (int i = 0; i < 8; ++i) h[i] = (_Float16)v[i]; *(half8*)((_Float16*)p + e) = h; }
+};
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    float v[4];
+    __device__ __forceinline__ void load(const void* p, size_t e) { float4 f = *(const float4*)((const float*)p + e); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+    __device__ __forceinline__ void store(void* p, size_t e) const { *(float4*)((float*)p + e) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// K4: y = relu(((base + up(z0)) + up(z1)) + up(z2)), bilinear align_corners=True
+//     (F.interpolate + sum + ReLU, eagle/models/keypoint_hrnet.py:290-309)
+// ------------------------------------------------------------------------------------------------------------
+struct FuseArgs { TView base, y; TView z[3]; int n_up; int relu; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
+{
+    constexpr int VN = Vec<T>::N;
+    const int H = a.y.h, W = a.y.w, groups = a.y.c / VN;
+    const size_t total = (size_t)a.y.n * H * W * groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const size_t pix = i / groups;
+        const int ox = (int)(pix % W);
+        const int oy = (int)((pix / W) % H);
+        const int n = (int)(pix / ((size_t)W * H));
+        Vec<T> acc; acc.load(a.base.p, pix * a.base.cs + a.base.off + g * VN);
+        for (int j = 0; j < a.n_up; ++j) {
+            const TView& z = a.z[j];
+            const float sh = (H > 1) ? (float)(z.h - 1) / (float)(H - 1) : 0.f;
+            const float sw = (W > 1) ? (float)(z.w - 1) / (float)(W - 1) : 0.f;
+            const float fy = sh * (float)oy, fx = sw * (float)ox;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < z.h - 1 ? 1 : 0), x1 = x0 + (x0 < z.w - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+            const size_t b = (size_t)n * z.h * z.w;
+            Vec<T> p00, p01, p10, p11;
+            p00.load(z.p, (b + (size_t)y0 * z.w + x0) * z.cs + z.off + g * VN);
+            p01.load(z.p, (b + (size_t)y0 * z.w + x1) * z.cs + z.off + g * VN);
+            p10.load(z.p, (b + (size_t)y1 * z.w + x0) * z.cs + z.off + g * VN);
+            p11.load(z.p, (b + (size_t)y1 * z.w + x1) * z.cs + z.off + g * VN);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) {
+                const float top = fmaf(lx1, p01.v[k], lx0 * p00.v[k]);
+                const float bot = fmaf(lx1, p11.v[k], lx0 * p10.v[k]);
+                acc.v[k] = acc.v[k] + fmaf(ly1, bot, ly0 * top);
+            }
+        }
+        if (a.relu)
+#pragma unroll
+            for (int k = 0; k < VN; ++k) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : 0.f;
+        acc.store(a.y.p, pix * a.y.cs + a.y.off + g * VN);
+    }
+}
+
+static int ew_blocks(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 256 * 16); }
+
+void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s)
+{
+    FuseArgs a; a.base = base; a.y = y; a.n_up = n_up; a.relu = relu;
+    for (int i = 0; i < n_up; ++i) a.z[i] = ups[i].z;
+    const int vn = y.f32 ? 4 : 8;
+    const size_t total = (size_t)y.n * y.h * y.w * (y.c / vn);
+    if (y.f32) hipLaunchKernelGGL(fuse_sum_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(fuse_sum_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K8: SPPF MaxPool2d(5,1,2) and nearest x2 upsample, reading/writing channel slices of concat buffers
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool5_kernel(TView x, TView y)
+{
+    constexpr int VN = Vec<T>::N;
+    const int H = x.h, W = x.w, groups = x.c / VN;
+    const size_t total = (size_t)x.n * H * W * groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const size_t pix = i / groups;
+        const int ox = (int)(pix % W), oy = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+        Vec<T> m;
+        for (int k = 0; k < VN; ++k) m.v[k] = -INFINITY;
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int iy = oy + dy;
+            if (iy < 0 || iy >= H) continue;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int ix = ox + dx;
+                if (ix < 0 || ix >= W) continue;
+                Vec<T> v; v.load(x.p, ((size_t)(n * H + iy) * W + ix) * x.cs + x.off + g * VN);
+                for (int k = 0; k < VN; ++k) m.v[k] = v.v[k] > m.v[k] ? v.v[k] : m.v[k];
+            }
+        }
+        m.store(y.p, pix * y.cs + y.off + g * VN);
+    }
+}
+void maxpool5_launch(const TView& x, const TView& y, hipStream_t s)
+{
+    const int vn = x.f32 ? 4 : 8;
+    const size_t total = (size_t)x.n * x.h * x.w * (x.c / vn);
+    if (x.f32) hipLaunchKernelGGL(maxpool5_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    else hipLaunchKernelGGL(maxpool5_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_kernel(TView x, TView y)
+{
+    constexpr int VN = Vec<T>::N;
+    const int H = y.h, W = y.w, groups = x.c / VN;
+    const size_t total = (size_t)y.n * H * W * groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const size_t pix = i / groups;
+        const int ox = (int)(pix % W), oy = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+        Vec<T> v; v.load(x.p, ((size_t)(n * x.h + oy / 2) * x.w + ox / 2) * x.cs + x.off + g * VN);
+        v.store(y.p, pix * y.cs + y.off + g * VN);
+    }
+}
+void upsample2_launch(const TView& x, const TView& y, hipStream_t s)
+{
+    const int vn = x.f32 ? 4 : 8;
+    const size_t total = (size_t)y.n * y.h * y.w * (x.c / vn);
+    if (x.f32) hipLaunchKernelGGL(upsample2_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    else hipLaunchKernelGGL(upsample2_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K5: per-channel first maximum of sigmoid(logits) over a pixel range (KeypointModel.get_keypoints,
+//     eagle/models/keypoint_hrnet.py:581-593: np.argmax of the sigmoid map = first maximum, row-major).
+//     Stage 1 of 2: grid (chunks, n); the per-frame post kernel reduces the chunk partials.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heat_argmax_kernel(TView lg, ArgmaxPart* parts, int chunks)
+{
+    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int HW = lg.h * lg.w;
+    const int per = (HW + chunks - 1) / chunks;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    const float* base = (const float*)lg.p + (size_t)n * HW * lg.cs + lg.off + c;
+    float best = -1.0f; int bi = 0x7fffffff;
+    for (int p = p0 + pl; p < p1; p += 4) {
+        const float sg = d_sigmoidf(base[(size_t)p * lg.cs]);
+        if (sg > best) { best = sg; bi = p; }
+    }
+    __shared__ float sb[256];
+    __shared__ int si[256];
+    sb[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < 4; ++k) {
+            const float ob = sb[k * 64 + c]; const int oi = si[k * 64 + c];
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        ArgmaxPart r; r.score = best; r.idx = bi;
+        parts[((size_t)n * chunks + chunk) * 64 + c] = r;
+    }
+}
+void heat_argmax_launch(const TView& logits, ArgmaxPart* parts, int chunks, hipStream_t s)
+{
+    hipLaunchKernelGGL(heat_argmax_kernel, dim3(chunks, logits.n), dim3(256), 0, s, logits, parts, chunks);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace eagle

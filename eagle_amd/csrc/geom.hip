@@ -1,0 +1,603 @@
+// Per-frame geometry on the GPU (K9/K10): one workgroup per frame turns the heat-map maxima into the reference's
+// keypoint dict, synthesises keypoints by line intersection, solves the image->pitch homography
+// (normalised DLT inside RANSAC + Levenberg-Marquardt polish, i.e. cv2.findHomography(src, dst, cv2.RANSAC, 5.0)),
+// projects every detection's foot point and the four image corners, and completes the fixed-size record.
+//
+// Replaces eagle/models/keypoint_hrnet.py:583-594 and eagle/models/coordinate_model.py:500-518 (decode, threshold,
+// dedup), :76-186 (synthesis, cv2.fitLine), :333-367 (findHomography), :369-392 (perspectiveTransform, astype(int),
+// bounds test), :396-414 + :32-44 (boundaries).  All float64 arithmetic below is written operation-for-operation
+// like oracle/eo_prims.c and built with -ffp-contract=off, so H and every integer derived from it can be compared
+// bit-for-bit.  RANSAC's sequential semantics are preserved: subsets are drawn serially from the MWC generator,
+// the 4-point models of a batch of iterations are solved in parallel (they do not depend on the running best),
+// and the batch is then replayed in iteration order with the adaptive iteration bound.
+#include "common.h"
+#include "pitch_table.h"
+
+namespace eagle {
+
+#define POST_T 256
+#define DEPS 2.220446049250313e-16
+
+// ---- 9x9 symmetric eigen-solve (cyclic Jacobi), eigenvector of the smallest eigenvalue ----------------------
+__device__ void jacobi9_smallest(double A[9][9], double v[9])
+{
+    double V[9][9];
+    for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 8; ++p) for (int q = p + 1; q < 9; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 9; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int i = 1; i < 9; ++i) if (A[i][i] < A[m][m]) m = i;
+    for (int k = 0; k < 9; ++k) v[k] = V[k][m];
+}
+
+// ---- normalised DLT ("runKernel") ---------------------------------------------------------------------------
+__device__ int dlt_homography(const double* src, const double* dst, const int* sel, int n, double* H)
+{
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        cM[0] += src[2 * k]; cM[1] += src[2 * k + 1]; cm[0] += dst[2 * k]; cm[1] += dst[2 * k + 1];
+    }
+    cM[0] /= n; cM[1] /= n; cm[0] /= n; cm[1] /= n;
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        sM[0] += fabs(src[2 * k] - cM[0]); sM[1] += fabs(src[2 * k + 1] - cM[1]);
+        sm[0] += fabs(dst[2 * k] - cm[0]); sm[1] += fabs(dst[2 * k + 1] - cm[1]);
+    }
+    if (fabs(sM[0]) < DEPS || fabs(sM[1]) < DEPS || fabs(sm[0]) < DEPS || fabs(sm[1]) < DEPS) return 0;
+    sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
+    double LtL[9][9];
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) LtL[a][b] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        const double X = (src[2 * k] - cM[0]) * sM[0], Y = (src[2 * k + 1] - cM[1]) * sM[1];
+        const double x = (dst[2 * k] - cm[0]) * sm[0], y = (dst[2 * k + 1] - cm[1]) * sm[1];
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int a = 0; a < 9; ++a) for (int b = a; b < 9; ++b) LtL[a][b] += Lx[a] * Lx[b] + Ly[a] * Ly[b];
+    }
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < a; ++b) LtL[a][b] = LtL[b][a];
+    double h[9];
+    jacobi9_smallest(LtL, h);
+    const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double t[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += iT[3 * r + k] * h[3 * k + c]; t[3 * r + c] = s; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += t[3 * r + k] * T[3 * k + c]; H[3 * r + c] = s; }
+    if (fabs(H[8]) < DEPS) return 0;
+    const double inv = 1.0 / H[8];
+    for (int k = 0; k < 9; ++k) H[k] *= inv;
+    H[8] = 1.0;
+    return 1;
+}
+
+__device__ __forceinline__ float reproj_err1(const double* src, const double* dst, int i, const double* H)
+{
+    const double X = src[2 * i], Y = src[2 * i + 1];
+    const double ww = 1.0 / (H[6] * X + H[7] * Y + 1.0);
+    const double dx = (H[0] * X + H[1] * Y + H[2]) * ww - dst[2 * i];
+    const double dy = (H[3] * X + H[4] * Y + H[5]) * ww - dst[2 * i + 1];
+    return (float)(dx * dx + dy * dy);
+}
+
+__device__ int collinear_last(const double* p, const int* idx, int count)
+{
+    const int i = count - 1;
+    for (int j = 0; j < i; ++j) {
+        const double dx1 = p[2 * idx[j]] - p[2 * idx[i]], dy1 = p[2 * idx[j] + 1] - p[2 * idx[i] + 1];
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = p[2 * idx[k]] - p[2 * idx[i]], dy2 = p[2 * idx[k] + 1] - p[2 * idx[i] + 1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return 1;
+        }
+    }
+    return 0;
+}
+__device__ int check_subset4(const double* src, const double* dst, const int* idx)
+{
+    for (int c = 3; c <= 4; ++c)
+        if (collinear_last(src, idx, c) || collinear_last(dst, idx, c)) return 0;
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int a = idx[tt[i][0]], b = idx[tt[i][1]], c = idx[tt[i][2]];
+        const double A = src[2 * a] * (src[2 * b + 1] - src[2 * c + 1]) - src[2 * a + 1] * (src[2 * b] - src[2 * c]) +
+                         (src[2 * b] * src[2 * c + 1] - src[2 * c] * src[2 * b + 1]);
+        const double B = dst[2 * a] * (dst[2 * b + 1] - dst[2 * c + 1]) - dst[2 * a + 1] * (dst[2 * b] - dst[2 * c]) +
+                         (dst[2 * b] * dst[2 * c + 1] - dst[2 * c] * dst[2 * b + 1]);
+        negative += (A * B < 0);
+    }
+    return negative == 0 || negative == 4;
+}
+__device__ __forceinline__ unsigned rng_next(unsigned long long* st)
+{
+    *st = (unsigned long long)(unsigned)(*st) * 4164903690ULL + (unsigned)(*st >> 32);
+    return (unsigned)(*st);
+}
+__device__ int ransac_update_iters(double p, double ep, int model_points, int max_iters)
+{
+    if (p < 0) p = 0; if (p > 1) p = 1;
+    if (ep < 0) ep = 0; if (ep > 1) ep = 1;
+    const double num0 = 1.0 - p;
+    const double num = num0 > 2.2250738585072014e-308 ? num0 : 2.2250738585072014e-308;
+    const double denom = 1.0 - pow(1.0 - ep, (double)model_points);
+    if (denom < 2.2250738585072014e-308) return 0;
+    const double ln = log(num), ld = log(denom);
+    return (ld >= 0 || -ln >= max_iters * (-ld)) ? max_iters : (int)lrint(ln / ld);
+}
+
+// ---- Levenberg-Marquardt polish ------------------------------------------------------------------------------
+__device__ void lm_residual(const double* src, const double* dst, int n, const double* h, double* r, double* J)
+{
+    for (int i = 0; i < n; ++i) {
+        const double Mx = src[2 * i], My = src[2 * i + 1];
+        double ww = h[6] * Mx + h[7] * My + 1.0;
+        ww = fabs(ww) > DEPS ? 1.0 / ww : 0.0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        r[2 * i] = xi - dst[2 * i]; r[2 * i + 1] = yi - dst[2 * i + 1];
+        if (J) {
+            double* a = J + (size_t)(2 * i) * 8; double* b = a + 8;
+            a[0] = Mx * ww; a[1] = My * ww; a[2] = ww; a[3] = a[4] = a[5] = 0.0;
+            a[6] = -Mx * ww * xi; a[7] = -My * ww * xi;
+            b[0] = b[1] = b[2] = 0.0; b[3] = Mx * ww; b[4] = My * ww; b[5] = ww;
+            b[6] = -Mx * ww * yi; b[7] = -My * ww * yi;
+        }
+    }
+}
+__device__ int solve8(double A[8][8], double b[8], double x[8])
+{
+    double M[8][9];
+    for (int i = 0; i < 8; ++i) { for (int j = 0; j < 8; ++j) M[i][j] = A[i][j]; M[i][8] = b[i]; }
+    for (int c = 0; c < 8; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 8; ++r) if (fabs(M[r][c]) > fabs(M[p][c])) p = r;
+        if (fabs(M[p][c]) < 1e-300) return 0;
+        if (p != c) for (int j = 0; j < 9; ++j) { const double t = M[c][j]; M[c][j] = M[p][j]; M[p][j] = t; }
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = M[r][c] / M[c][c];
+            for (int j = c; j < 9; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 7; i >= 0; --i) {
+        double s = M[i][8];
+        for (int j = i + 1; j < 8; ++j) s -= M[i][j] * x[j];
+        x[i] = s / M[i][i];
+    }
+    return 1;
+}
+__device__ const double D_P10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5,
+                                     1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10,
+                                     1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
+// r, rn: 2n doubles; J: 16n doubles (caller-provided scratch)
+__device__ void lm_refine(const double* src, const double* dst, int n, double* H, int max_iters, double* r, double* rn, double* J)
+{
+    double h[8];
+    for (int k = 0; k < 8; ++k) h[k] = H[k];
+    lm_residual(src, dst, n, h, r, J);
+    double S = 0;
+    for (int i = 0; i < 2 * n; ++i) S += r[i] * r[i];
+    int lambdaLg10 = -3;
+    for (int it = 0; it < max_iters; ++it) {
+        double A[8][8], g[8];
+        for (int a = 0; a < 8; ++a) {
+            g[a] = 0;
+            for (int i = 0; i < 2 * n; ++i) g[a] += J[(size_t)i * 8 + a] * r[i];
+            for (int b = 0; b < 8; ++b) { double s = 0; for (int i = 0; i < 2 * n; ++i) s += J[(size_t)i * 8 + a] * J[(size_t)i * 8 + b]; A[a][b] = s; }
+        }
+        int improved = 0;
+        for (int tries = 0; tries < 16 && !improved; ++tries) {
+            double Ap[8][8], d[8], hn[8], gm[8];
+            const double lam = D_P10[lambdaLg10 + 16];
+            for (int a = 0; a < 8; ++a) { for (int b = 0; b < 8; ++b) Ap[a][b] = A[a][b]; Ap[a][a] += lam * A[a][a]; gm[a] = -g[a]; }
+            if (!solve8(Ap, gm, d)) { lambdaLg10 = lambdaLg10 + 1 > 16 ? 16 : lambdaLg10 + 1; continue; }
+            for (int k = 0; k < 8; ++k) hn[k] = h[k] + d[k];
+            lm_residual(src, dst, n, hn, rn, nullptr);
+            double Sn = 0;
+            for (int i = 0; i < 2 * n; ++i) Sn += rn[i] * rn[i];
+            if (Sn < S) {
+                for (int k = 0; k < 8; ++k) h[k] = hn[k];
+                S = Sn; improved = 1;
+                lambdaLg10 = lambdaLg10 - 1 < -16 ? -16 : lambdaLg10 - 1;
+            } else {
+                lambdaLg10 = lambdaLg10 + 1 > 16 ? 16 : lambdaLg10 + 1;
+            }
+        }
+        if (!improved) break;
+        lm_residual(src, dst, n, h, r, J);
+    }
+    for (int k = 0; k < 8; ++k) H[k] = h[k];
+    H[8] = 1.0;
+}
+
+// ---- workgroup-level findHomography(RANSAC) -------------------------------------------------------------------
+struct HomoShared {
+    double src[2 * EAGLE_MAX_KP], dst[2 * EAGLE_MAX_KP];
+    double s2[2 * EAGLE_MAX_KP], d2[2 * EAGLE_MAX_KP];
+    double cand[POST_T][9];
+    double best[9];
+    double lm_r[2 * EAGLE_MAX_KP], lm_rn[2 * EAGLE_MAX_KP], lm_J[16 * EAGLE_MAX_KP];
+    int subset[POST_T][4];
+    int good[POST_T];
+    signed char state[POST_T];     // 0: no subset found, 1: DLT failed, 2: model ok
+    unsigned char mask[EAGLE_MAX_KP];
+    int niters, max_good, ok, stop;
+    unsigned long long rng;
+};
+
+// img/world: float [n][2].  On return (after a barrier) S.ok, S.best, S.mask are valid for every thread.
+__device__ void find_homography_block(HomoShared& S, const float* img, const float* world, int n, double thresh,
+                                      int max_iters, int lm_iters)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * n; i += POST_T) { S.src[i] = (double)img[i]; S.dst[i] = (double)world[i]; }
+    if (tid == 0) { S.ok = 0; S.niters = max_iters; S.max_good = 0; S.stop = 0; S.rng = 0xffffffffffffffffULL; }
+    __syncthreads();
+    if (n < 4) return;
+    if (n == 4) {
+        if (tid == 0) {
+            double Hc[9];
+            S.ok = dlt_homography(S.src, S.dst, nullptr, 4, Hc);
+            for (int k = 0; k < 9; ++k) S.best[k] = Hc[k];
+            for (int i = 0; i < n; ++i) S.mask[i] = 1;
+        }
+        __syncthreads();
+        return;
+    }
+    const float t2 = (float)(thresh * thresh);
+    for (int base = 0; ; base += POST_T) {
+        if (base >= S.niters || S.stop) break;        // uniform (shared values, read after a barrier)
+        if (tid == 0) {                              // draw the subsets of iterations [base, base+POST_T) serially
+            unsigned long long rng = S.rng;
+            int k = 0;
+            for (; k < POST_T && base + k < S.niters; ++k) {
+                int idx[4], found = 0;
+                for (int attempt = 0; attempt < 1000 && !found; ++attempt) {
+                    for (int i = 0; i < 4; ++i) {
+                        int v, dup;
+                        do {
+                            v = (int)(rng_next(&rng) % (unsigned)n);
+                            dup = 0;
+                            for (int j = 0; j < i; ++j) dup |= (idx[j] == v);
+                        } while (dup);
+                        idx[i] = v;
+                    }
+                    found = check_subset4(S.src, S.dst, idx);
+                }
+                S.state[k] = found ? 1 : 0;
+                for (int i = 0; i < 4; ++i) S.subset[k][i] = idx[i];
+                if (!found) { ++k; break; }
+            }
+            for (; k < POST_T; ++k) S.state[k] = -1;   // beyond the iteration bound / after a failed draw
+            S.rng = rng;
+        }
+        __syncthreads();
+        if (S.state[tid] == 1) {
+            double Hc[9];
+            int idx[4] = {S.subset[tid][0], S.subset[tid][1], S.subset[tid][2], S.subset[tid][3]};
+            if (dlt_homography(S.src, S.dst, idx, 4, Hc)) {
+                int good = 0;
+                for (int i = 0; i < n; ++i) good += (reproj_err1(S.src, S.dst, i, Hc) <= t2);
+                S.good[tid] = good;
+                for (int k = 0; k < 9; ++k) S.cand[tid][k] = Hc[k];
+                S.state[tid] = 2;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {                              // replay in iteration order
+            for (int k = 0; k < POST_T; ++k) {
+                const int iter = base + k;
+                if (iter >= S.niters) break;
+                const int st = S.state[k];
+                if (st < 0) break;
+                if (st == 0) { if (iter == 0) S.max_good = -1; S.stop = 1; break; }
+                if (st == 1) continue;
+                const int good = S.good[k];
+                if (good > (S.max_good > 3 ? S.max_good : 3)) {
+                    for (int j = 0; j < 9; ++j) S.best[j] = S.cand[k][j];
+                    S.max_good = good;
+                    S.niters = ransac_update_iters(0.995, (double)(n - good) / n, 4, S.niters);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (S.max_good <= 0) return;                      // S.ok == 0
+    for (int i = tid; i < n; i += POST_T) S.mask[i] = reproj_err1(S.src, S.dst, i, S.best) <= t2;
+    __syncthreads();
+    if (tid == 0) {
+        int ni = 0;
+        for (int i = 0; i < n; ++i)
+            if (S.mask[i]) { S.s2[2 * ni] = S.src[2 * i]; S.s2[2 * ni + 1] = S.src[2 * i + 1]; S.d2[2 * ni] = S.dst[2 * i]; S.d2[2 * ni + 1] = S.dst[2 * i + 1]; ++ni; }
+        double Hr[9];
+        if (dlt_homography(S.s2, S.d2, nullptr, ni, Hr)) {
+            for (int k = 0; k < 9; ++k) S.best[k] = Hr[k];
+            if (lm_iters > 0) {
+                lm_refine(S.s2, S.d2, ni, Hr, lm_iters, S.lm_r, S.lm_rn, S.lm_J);
+                for (int k = 0; k < 9; ++k) S.best[k] = Hr[k];
+            }
+        }
+        S.ok = 1;
+    }
+    __syncthreads();
+}
+
+// ---- cv2.fitLine(DIST_L2) closed form and the 2x2 intersection -------------------------------------------------
+__device__ bool fit_line(const float* pts, int n, double line[4])
+{
+    double x = 0, y = 0, x2 = 0, y2 = 0, xy = 0;
+    for (int i = 0; i < n; ++i) {
+        const double px = pts[2 * i], py = pts[2 * i + 1];
+        x += px; y += py; x2 += px * px; y2 += py * py; xy += px * py;
+    }
+    const double w = (double)n;
+    x /= w; y /= w; x2 /= w; y2 /= w; xy /= w;
+    const double dx2 = x2 - x * x, dy2 = y2 - y * y, dxy = xy - x * y;
+    const float t = (float)atan2(2 * dxy, dx2 - dy2) / 2;
+    line[0] = (double)(float)cos((double)t); line[1] = (double)(float)sin((double)t);
+    line[2] = (double)(float)x; line[3] = (double)(float)y;
+    return !(fabs(line[0]) + fabs(line[1]) < 1e-6);
+}
+__device__ bool intersect_lines(const double* l1, const double* l2, double* px, double* py)
+{
+    const double vx1 = l1[0], vy1 = l1[1], x01 = l1[2], y01 = l1[3];
+    const double vx2 = l2[0], vy2 = l2[1], x02 = l2[2], y02 = l2[3];
+    const double det = vx1 * (-vy2) - vy1 * (-vx2);
+    if (fabs(det) < 1e-8) return false;
+    double a00 = vx1, a01 = -vx2, a10 = vy1, a11 = -vy2, b0 = x02 - x01, b1 = y02 - y01;
+    if (fabs(a10) > fabs(a00)) {
+        double t;
+        t = a00; a00 = a10; a10 = t; t = a01; a01 = a11; a11 = t; t = b0; b0 = b1; b1 = t;
+    }
+    if (a00 == 0.0) return false;
+    const double l = a10 * (1.0 / a00);
+    const double u11 = a11 - l * a01;
+    if (u11 == 0.0) return false;
+    const double t1 = (b1 - l * b0) / u11;
+    const double t = (b0 - a01 * t1) / a00;
+    *px = x01 + t * vx1; *py = y01 + t * vy1;
+    return true;
+}
+
+// ---- the per-frame kernel ---------------------------------------------------------------------------------------
+struct PostShared {
+    HomoShared hs;
+    int hm_idx[64]; float hm_score[64];
+    EagleKeypoint kp[EAGLE_MAX_KP];
+    int nkp;
+    float img[2 * EAGLE_MAX_KP], world[2 * EAGLE_MAX_KP];
+    int used[EAGLE_MAX_KP];
+    int npts;
+    double H[9]; int H_ok;
+};
+
+struct PostArgs { const ArgmaxPart* parts; PostParams pp; EagleFrameResult* out; };
+
+__device__ __forceinline__ void persp(const double* H, float fx, float fy, float* ox, float* oy)
+{
+    const double x = fx, y = fy;
+    double w = H[6] * x + H[7] * y + H[8];
+    if (fabs(w) > DEPS) {
+        w = 1.0 / w;
+        *ox = (float)((H[0] * x + H[1] * y + H[2]) * w);
+        *oy = (float)((H[3] * x + H[4] * y + H[5]) * w);
+    } else {
+        *ox = 0.f; *oy = 0.f;
+    }
+}
+
+__device__ bool find_x_at_y(double x1, double y1, double x2, double y2, double yt, double* out)
+{
+    if (x2 - x1 == 0.0) return false;
+    const double m = (y2 - y1) / (x2 - x1);
+    const double c = y1 - m * x1;
+    if (m == 0.0) return false;
+    *out = (yt - c) / m;
+    return true;
+}
+
+__global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PostShared& S = *(PostShared*)smem;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const PostParams& pp = a.pp;
+    EagleFrameResult* R = a.out + f;
+
+    // (1) reduce the per-chunk heat-map maxima: first maximum wins (kh.py:588)
+    if (tid < 64) {
+        float best = -1.f; int bi = 0;
+        for (int c = 0; c < pp.hm_chunks; ++c) {
+            const ArgmaxPart p = a.parts[((size_t)f * pp.hm_chunks + c) * 64 + tid];
+            if (p.score > best) { best = p.score; bi = p.idx; }
+        }
+        S.hm_idx[tid] = bi; S.hm_score[tid] = best;
+        if (tid < EAGLE_N_LANDMARKS) { R->hm_idx[tid] = bi; R->hm_score[tid] = best; }
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        // (2) threshold / pixel mapping / same-pixel dedup (kh.py:590-593, cm.py:500-518)
+        int lx[57], ly[57], q[57], nq = 0;
+        for (int i = 0; i < 57; ++i) {
+            const double s = (double)S.hm_score[i];
+            if (!(s > 0.01)) continue;
+            if (s < pp.keypoint_conf) continue;
+            const int py = S.hm_idx[i] / pp.hm_w, px = S.hm_idx[i] - py * pp.hm_w;
+            const double xn = (double)px / (double)(pp.hm_w - 1 > 1 ? pp.hm_w - 1 : 1);
+            const double yn = (double)py / (double)(pp.hm_h - 1 > 1 ? pp.hm_h - 1 : 1);
+            lx[i] = (int)(xn * (double)pp.frame_w); ly[i] = (int)(yn * (double)pp.frame_h);
+            q[nq++] = i;
+        }
+        int nkp = 0;
+        for (int a_ = 0; a_ < nq; ++a_) {
+            const int i = q[a_];
+            int count = 0; float mx = -1.f;
+            for (int b_ = 0; b_ < nq; ++b_) {
+                const int j = q[b_];
+                if (lx[j] == lx[i] && ly[j] == ly[i]) { ++count; mx = S.hm_score[j] > mx ? S.hm_score[j] : mx; }
+            }
+            if (count > 1 && S.hm_score[i] != mx) continue;
+            int slot = -1;
+            for (int k = 0; k < nkp; ++k) if (S.kp[k].x == lx[i] && S.kp[k].y == ly[i]) slot = k;
+            if (slot < 0) slot = nkp++;
+            EagleKeypoint kp; kp.label = i; kp.x = lx[i]; kp.y = ly[i]; kp.score = S.hm_score[i];
+            kp.synthesized = 0; kp.on_plane = 0; kp.inlier = 0; kp.pad = 0;
+            S.kp[slot] = kp;
+        }
+        // (3) synthesis by line intersection (cm.py:140-186), only with >= 2 keypoints (cm.py:326)
+        if (nkp >= 2) {
+            signed char slot_of[57];
+            for (int i = 0; i < 57; ++i) slot_of[i] = -1;
+            for (int k = 0; k < nkp; ++k) slot_of[S.kp[k].label] = (signed char)k;
+            double ylines[PT_NY][4], xlines[PT_NX][4];
+            bool yok[PT_NY], xok[PT_NX];
+            for (int pass = 0; pass < 2; ++pass) {
+                const int ng = pass == 0 ? PT_NY : PT_NX;
+                for (int g = 0; g < ng; ++g) {
+                    float pts[2 * PT_MAXG]; int np = 0;
+                    for (int m = 0; m < PT_MAXG; ++m) {
+                        const int lab = pass == 0 ? PT_YGROUP[g][m] : PT_XGROUP[g][m];
+                        if (lab < 0) break;
+                        if (PT_NOT_ON_PLANE_IDX[lab]) continue;
+                        const int sl = slot_of[lab];
+                        if (sl < 0) continue;
+                        pts[2 * np] = (float)S.kp[sl].x; pts[2 * np + 1] = (float)S.kp[sl].y; ++np;
+                    }
+                    bool ok = false;
+                    double line[4] = {0, 0, 0, 0};
+                    if (np >= 2) ok = fit_line(pts, np, line);
+                    if (pass == 0) { yok[g] = ok; for (int k = 0; k < 4; ++k) ylines[g][k] = line[k]; }
+                    else { xok[g] = ok; for (int k = 0; k < 4; ++k) xlines[g][k] = line[k]; }
+                }
+            }
+            int added = 0;
+            for (int gy = 0; gy < PT_NY && added < 30; ++gy) {
+                if (!yok[gy]) continue;
+                for (int gx = 0; gx < PT_NX; ++gx) {
+                    if (!xok[gx]) continue;
+                    const int lab = PT_CROSS[gy][gx];
+                    if (lab < 0 || slot_of[lab] >= 0) continue;
+                    double px, py;
+                    if (!intersect_lines(ylines[gy], xlines[gx], &px, &py)) continue;
+                    EagleKeypoint kp; kp.label = lab; kp.x = (int)rint(px); kp.y = (int)rint(py); kp.score = 0.f;
+                    kp.synthesized = 1; kp.on_plane = 0; kp.inlier = 0; kp.pad = 0;
+                    slot_of[lab] = (signed char)nkp;
+                    S.kp[nkp++] = kp;
+                    if (++added >= 30) break;
+                }
+            }
+        }
+        S.nkp = nkp;
+        // (4) on-plane selection (cm.py:338-349): float32 image and world points
+        int np = 0;
+        for (int k = 0; k < nkp; ++k) {
+            const int lab = S.kp[k].label;
+            if (!PT_ON_PLANE[lab]) continue;
+            S.kp[k].on_plane = 1;
+            S.img[2 * np] = (float)S.kp[k].x; S.img[2 * np + 1] = (float)S.kp[k].y;
+            S.world[2 * np] = (float)PT_WORLD[lab][0]; S.world[2 * np + 1] = (float)PT_WORLD[lab][1];
+            S.used[np] = k; ++np;
+        }
+        S.npts = np;
+    }
+    __syncthreads();
+
+    // (5) homography
+    find_homography_block(S.hs, S.img, S.world, S.npts, pp.ransac_thresh, pp.ransac_max_iters, pp.lm_iters);
+    __syncthreads();
+    const bool Hok = S.npts >= 4 && S.hs.ok;
+    if (tid == 0) {
+        for (int k = 0; k < 9; ++k) { S.H[k] = Hok ? S.hs.best[k] : 0.0; R->H[k] = S.H[k]; }
+        R->H_valid = Hok; R->pad[0] = R->pad[1] = 0;
+        if (Hok) for (int i = 0; i < S.npts; ++i) S.kp[S.used[i]].inlier = S.hs.mask[i];
+        R->n_kp = S.nkp;
+        // (7) boundaries (cm.py:396-414)
+        bool bok = false;
+        double bx[4] = {0, 0, 0, 0};
+        if (Hok) {
+            float cx[4], cy[4];
+            persp(S.H, 0.f, 0.f, &cx[0], &cy[0]);
+            persp(S.H, (float)pp.frame_w, 0.f, &cx[1], &cy[1]);
+            persp(S.H, 0.f, (float)pp.frame_h, &cx[2], &cy[2]);
+            persp(S.H, (float)pp.frame_w, (float)pp.frame_h, &cx[3], &cy[3]);
+            const double tlx = (int)cx[0], tly = (int)cy[0], trx = (int)cx[1], try_ = (int)cy[1];
+            const double blx = (int)cx[2], bly = (int)cy[2], brx = (int)cx[3], bry = (int)cy[3];
+            double ntl, ntr, nbl, nbr;
+            bok = find_x_at_y(tlx, tly, blx, bly, 68.0, &ntl) && find_x_at_y(trx, try_, brx, bry, 68.0, &ntr) &&
+                  find_x_at_y(blx, bly, ntl, 68.0, 0.0, &nbl) && find_x_at_y(brx, bry, ntr, 68.0, 0.0, &nbr);
+            if (bok) { bx[0] = nbl; bx[1] = ntl; bx[2] = ntr; bx[3] = nbr; }
+        }
+        R->bounds_valid = bok;
+        for (int k = 0; k < 4; ++k) R->bounds[k] = bx[k];
+    }
+    __syncthreads();
+    for (int k = tid; k < S.nkp; k += POST_T) R->kp[k] = S.kp[k];
+    // (6) projection of foot points (cm.py:369-392)
+    const int nd = R->n_det;
+    for (int k = tid; k < nd; k += POST_T) {
+        EagleDet* d = &R->det[k];
+        float ox = 0.f, oy = 0.f; int tx = 0, ty = 0; unsigned char inb = 0;
+        if (Hok) {
+            persp(S.H, (float)d->foot_x, (float)d->foot_y, &ox, &oy);
+            tx = (int)ox; ty = (int)oy;
+            inb = !(tx < 0 || tx > 105 || ty < 0 || ty > 68);
+        }
+        d->pitch_xf = ox; d->pitch_yf = oy; d->pitch_x = tx; d->pitch_y = ty; d->in_bounds = inb;
+    }
+}
+
+void post_launch(const ArgmaxPart* parts, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s)
+{
+    PostArgs a; a.parts = parts; a.pp = pp; a.out = d_out;
+    static bool done = false;
+    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PostShared))); done = true; }
+    hipLaunchKernelGGL(post_kernel, dim3(n), dim3(POST_T), sizeof(PostShared), s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+// operator-level entry for the parity tests: findHomography only
+struct HomoArgs { const float* img; const float* world; int n; double thresh; int max_iters, lm_iters; double* H; uint8_t* mask; int* ok; };
+__global__ __launch_bounds__(POST_T) void homography_kernel(HomoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    HomoShared& S = *(HomoShared*)smem;
+    find_homography_block(S, a.img, a.world, a.n, a.thresh, a.max_iters, a.lm_iters);
+    __syncthreads();
+    const bool ok = a.n >= 4 && S.ok;
+    if (threadIdx.x == 0) { *a.ok = ok; for (int k = 0; k < 9; ++k) a.H[k] = ok ? S.best[k] : 0.0; }
+    for (int i = threadIdx.x; i < a.n; i += POST_T) a.mask[i] = ok ? S.mask[i] : 0;
+}
+void homography_only_launch(const float* d_img, const float* d_world, int npts, double thresh, int max_iters, int lm_iters,
+                            double* d_H, uint8_t* d_mask, int* d_ok, hipStream_t s)
+{
+    HomoArgs a{d_img, d_world, npts, thresh, max_iters, lm_iters, d_H, d_mask, d_ok};
+    static bool done = false;
+    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)homography_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HomoShared))); done = true; }
+    hipLaunchKernelGGL(homography_kernel, dim3(1), dim3(POST_T), sizeof(HomoShared), s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace eagle

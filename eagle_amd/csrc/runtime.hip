@@ -1,0 +1,920 @@
+// Host runtime behind the C ABI (include/eagle.h): weight store + BatchNorm folding, static launch schedule for
+// HRNet-W48 (+head) and YOLOv8-{n,s,m,l,x} built once per handle, per-batch execution on HIP streams (optionally
+// replayed as a hipGraph), record transfer and the RCCL gather.  No torch, no MIOpen/hipBLASLt: every kernel launched
+// here is one of this library's own (conv.hip, elementwise.hip, detect.hip, geom.hip).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace eagle {
+
+void fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw Err{code, buf};
+}
+
+static thread_local std::string g_create_error;
+
+struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
+
+// ------------------------------------------------------------------------------------------------------------
+struct Op {
+    enum Kind { CONV, OTHER } kind = OTHER;
+    std::function<void(hipStream_t)> run;
+    double flop = 0;
+    const char* tag = "";
+};
+
+struct Net {                      // one launch schedule + the device memory it owns
+    std::vector<Op> ops;
+    std::vector<void*> owned;
+    std::multimap<size_t, void*> free_list;
+    std::map<void*, size_t> sizes;
+    size_t bytes = 0;
+    ~Net() { for (void* p : owned) (void)hipFree(p); }
+    void* get(size_t b)
+    {
+        b = (b + 255) & ~(size_t)255;
+        auto it = free_list.find(b);
+        if (it != free_list.end()) { void* p = it->second; free_list.erase(it); return p; }
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, b));
+        HIP_CHECK(hipMemset(p, 0, b));
+        owned.push_back(p); sizes[p] = b; bytes += b;
+        return p;
+    }
+    void put(void* p) { if (p) free_list.insert({sizes.at(p), p}); }
+    void* upload(const void* src, size_t b)
+    {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<size_t>(b, 16)));
+        HIP_CHECK(hipMemcpy(p, src, b, hipMemcpyHostToDevice));
+        owned.push_back(p); bytes += b;
+        return p;
+    }
+};
+
+}  // namespace eagle
+
+using namespace eagle;
+
+struct EagleHandle {
+    EagleConfig cfg;
+    std::string err;
+    std::map<std::string, HostTensor> weights;
+    bool finalized = false;
+    int prec = 0;
+    hipStream_t s_main = nullptr, s_det = nullptr;
+    hipEvent_t ev_pre = nullptr, ev_det = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    std::unique_ptr<Net> hr, yo, misc;
+    // step buffers
+    uint8_t* d_frames = nullptr;          // [batch,h,w,3] staging for host-fed frames
+    TView kp_in, det_in, logits;
+    LetterBox lb;
+    ArgmaxPart* d_parts = nullptr;
+    int hm_chunks = 64;
+    DetScratch ds;
+    DetLevel levels[3];
+    EagleFrameResult* d_out = nullptr;
+    EagleFrameResult* h_out = nullptr;    // pinned
+    PostParams pp;
+    // graph
+    hipGraphExec_t gexec = nullptr;
+    const uint8_t* g_src = nullptr; int g_n = 0; bool warmed = false;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> conv_ev;
+    EagleTimings timings{};
+    double conv_flop_step = 0; int n_conv = 0, n_launch = 0;
+    // comm
+    void* rccl = nullptr; void* comm = nullptr; int rank = 0, world = 1;
+};
+
+namespace eagle {
+
+// ------------------------------------------------------------------------------------------------------------
+// Builder: shared by both networks
+// ------------------------------------------------------------------------------------------------------------
+struct Builder {
+    EagleHandle* H;
+    Net* net;
+    int prec;
+    double bn_eps;
+    int N;
+
+    int gran() const { return prec == EAGLE_PREC_F16 ? 8 : 4; }
+
+    TView act(int h, int w, int c, bool f32 = false)
+    {
+        TView v; v.n = N; v.h = h; v.w = w; v.c = c; v.cs = c; v.off = 0;
+        v.f32 = (f32 || prec == EAGLE_PREC_F32) ? 1 : 0;
+        v.p = net->get((size_t)N * h * w * c * v.esize());
+        return v;
+    }
+    void release(const TView& v) { net->put(v.p); }
+
+    const HostTensor& W(const std::string& name)
+    {
+        auto it = H->weights.find(name);
+        if (it == H->weights.end()) fail(EAGLE_E_MISSING, "weight tensor '%s' was not loaded", name.c_str());
+        return it->second;
+    }
+
+    // conv (+ folded BN when bn != ""), output into `out` if given (a slice of a concat buffer), else a new tensor.
+    TView conv(const TView& x, const std::string& cname, const std::string& bn, int stride, int pre, const TView* r1,
+               const TView* r2, int post, const TView* out = nullptr, bool out_f32 = false)
+    {
+        const HostTensor& w = W(cname + ".weight");
+        if (w.shape.size() != 4) fail(EAGLE_E_INVALID, "%s.weight: expected 4-d", cname.c_str());
+        const int cout = (int)w.shape[0], cin = (int)w.shape[1], ks = (int)w.shape[2];
+        if (cin > x.c) fail(EAGLE_E_INVALID, "%s: input has %d channels, weight expects %d", cname.c_str(), x.c, cin);
+        const int cout_pad = (cout + 15) / 16 * 16;
+        // fold: scale = gamma / sqrt(var + eps) (float64); w' = f32(f64(w)*scale); b' = f32(beta - mean*scale)
+        std::vector<float> hwio((size_t)ks * ks * cin * cout), bias(cout_pad, 0.f);
+        std::vector<double> scale(cout, 1.0);
+        if (!bn.empty()) {
+            const HostTensor &g = W(bn + ".weight"), &b = W(bn + ".bias"), &m = W(bn + ".running_mean"), &v = W(bn + ".running_var");
+            for (int o = 0; o < cout; ++o) {
+                scale[o] = (double)g.data[o] / std::sqrt((double)v.data[o] + bn_eps);
+                bias[o] = (float)((double)b.data[o] - (double)m.data[o] * scale[o]);
+            }
+        } else {
+            const HostTensor& b = W(cname + ".bias");
+            for (int o = 0; o < cout; ++o) bias[o] = b.data[o];
+        }
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin; ++i)
+                for (int t = 0; t < ks * ks; ++t) {
+                    const float wv = w.data[((size_t)o * cin + i) * ks * ks + t];
+                    hwio[((size_t)t * cin + i) * cout + o] = bn.empty() ? wv : (float)((double)wv * scale[o]);
+                }
+        const int ho = (x.h + 2 * (ks / 2) - ks) / stride + 1, wo = (x.w + 2 * (ks / 2) - ks) / stride + 1;
+        ConvLaunch L;
+        L.cfg = conv_choose(prec, ks, stride, x.c, cout_pad, wo);
+        if (!conv_supported(prec, L.cfg))
+            fail(EAGLE_E_NOKERNEL, "%s: no kernel instance (ks=%d s=%d kc=%d nt=%d)", cname.c_str(), ks, stride, L.cfg.kc, L.cfg.nt);
+        const size_t ne = conv_weight_elems(prec, L.cfg);
+        std::vector<char> tiled(ne * (prec == EAGLE_PREC_F16 ? 2 : 4));
+        conv_tile_weights(prec, L.cfg, hwio.data(), cin, cout, tiled.data());
+        L.w = net->upload(tiled.data(), tiled.size());
+        L.bias = (const float*)net->upload(bias.data(), bias.size() * 4);
+        L.x = x;
+        if (out) {
+            L.y = *out;
+            if (out->c != cout_pad || out->h != ho || out->w != wo) fail(EAGLE_E_INVALID, "%s: output slice mismatch", cname.c_str());
+        } else {
+            L.y = act(ho, wo, cout_pad, out_f32);
+        }
+        if (r1) L.r1 = *r1;
+        if (r2) L.r2 = *r2;
+        L.pre_act = pre; L.post_act = post; L.out_f32 = out_f32 ? 1 : 0;
+        L.flop = 2.0 * N * ho * wo * (double)cout * cin * ks * ks;
+        const int pr = prec;
+        Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = "conv";
+        op.run = [L, pr](hipStream_t s) { conv_launch(pr, L, s); };
+        net->ops.push_back(op);
+        return L.y;
+    }
+    void other(std::function<void(hipStream_t)> fn, const char* tag)
+    {
+        Op op; op.kind = Op::OTHER; op.run = std::move(fn); op.tag = tag;
+        net->ops.push_back(op);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// HRNet-W48 + head (eagle/models/keypoint_hrnet.py:315-351, 444-481, 283-309, 553-562).  The fusion plan
+// (which adds ride in which epilogue) is the one oracle/nets.py::_hr_stage mirrors.
+// ------------------------------------------------------------------------------------------------------------
+static const char* HRP = "unnormalized_model.0.";
+
+static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_idx, int n_modules, int nb, bool last_single)
+{
+    const int R = ACT_RELU;
+    for (int m = 0; m < n_modules; ++m) {
+        const std::string q = std::string(HRP) + "stage" + std::to_string(stage_idx) + "." + std::to_string(m) + ".";
+        for (int b = 0; b < nb; ++b) {
+            TView x = xs[b];
+            for (int k = 0; k < 4; ++k) {
+                const std::string r = q + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
+                TView o = B.conv(x, r + "conv1", r + "bn1", 1, 0, nullptr, nullptr, R);
+                TView y = B.conv(o, r + "conv2", r + "bn2", 1, 0, &x, nullptr, R);
+                B.release(o);
+                B.release(x);
+                x = y;
+            }
+            xs[b] = x;
+        }
+        const int n_out = (last_single && m == n_modules - 1) ? 1 : nb;
+        std::vector<TView> out;
+        for (int i = 0; i < n_out; ++i) {
+            TView y; bool have_y = false;
+            for (int j = 0; j < i; ++j) {
+                TView t = xs[j];
+                for (int k = 0; k < i - j; ++k) {
+                    const std::string r = q + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(k) + ".";
+                    const bool last = k == i - j - 1;
+                    TView nt;
+                    if (!last) {
+                        nt = B.conv(t, r + "0", r + "1", 2, 0, nullptr, nullptr, R);
+                    } else {
+                        const TView* ident = (j == i - 1) ? &xs[i] : nullptr;
+                        const bool relu_now = ident && i == nb - 1;
+                        nt = B.conv(t, r + "0", r + "1", 2, 0, have_y ? &y : nullptr, ident, relu_now ? R : 0);
+                    }
+                    if (k > 0) B.release(t);
+                    t = nt;
+                }
+                if (have_y) B.release(y);
+                y = t; have_y = true;
+            }
+            if (i == 0) y = xs[0];
+            FuseUp ups[3]; int nu = 0;
+            for (int j = i + 1; j < nb; ++j) {
+                const std::string r = q + "fuse_layers." + std::to_string(i) + "." + std::to_string(j) + ".";
+                ups[nu++].z = B.conv(xs[j], r + "0", r + "1", 1, 0, nullptr, nullptr, 0);
+            }
+            if (nu) {
+                TView o = B.act(y.h, y.w, y.c);
+                const TView base = y; FuseUp u0 = ups[0], u1 = ups[1], u2 = ups[2]; const int n_up = nu;
+                B.other([base, u0, u1, u2, n_up, o](hipStream_t s) { FuseUp u[3] = {u0, u1, u2}; fuse_sum_launch(base, u, n_up, 1, o, s); }, "fuse");
+                for (int k = 0; k < nu; ++k) B.release(ups[k].z);
+                if (i != 0) B.release(y);
+                y = o;
+            }
+            out.push_back(y);
+        }
+        // inputs of this module's fuse are dead now (xs[0] may be aliased by out[0] only when nb == 1, never here)
+        for (int b = 0; b < nb; ++b) B.release(xs[b]);
+        xs = out;
+    }
+    return xs;
+}
+
+static TView build_hrnet(Builder& B, const TView& x_in)
+{
+    const int R = ACT_RELU;
+    const std::string P = HRP;
+    TView x = B.conv(x_in, P + "conv1", P + "bn1", 2, 0, nullptr, nullptr, R);
+    TView x2 = B.conv(x, P + "conv2", P + "bn2", 2, 0, nullptr, nullptr, R);
+    B.release(x); x = x2;
+    for (int b = 0; b < 4; ++b) {
+        const std::string q = P + "layer1." + std::to_string(b) + ".";
+        TView res = x;
+        if (b == 0) res = B.conv(x, q + "downsample.0", q + "downsample.1", 1, 0, nullptr, nullptr, 0);
+        TView o1 = B.conv(x, q + "conv1", q + "bn1", 1, 0, nullptr, nullptr, R);
+        TView o2 = B.conv(o1, q + "conv2", q + "bn2", 1, 0, nullptr, nullptr, R);
+        TView y = B.conv(o2, q + "conv3", q + "bn3", 1, 0, &res, nullptr, R);
+        B.release(o1); B.release(o2);
+        if (b == 0) B.release(res);
+        B.release(x);
+        x = y;
+    }
+    std::vector<TView> ys;
+    ys.push_back(B.conv(x, P + "transition1.0.0", P + "transition1.0.1", 1, 0, nullptr, nullptr, R));
+    ys.push_back(B.conv(x, P + "transition1.1.0.0", P + "transition1.1.0.1", 2, 0, nullptr, nullptr, R));
+    B.release(x);
+    ys = hr_stage(B, ys, 2, 1, 2, false);
+    ys.push_back(B.conv(ys.back(), P + "transition2.2.0.0", P + "transition2.2.0.1", 2, 0, nullptr, nullptr, R));
+    ys = hr_stage(B, ys, 3, 4, 3, false);
+    ys.push_back(B.conv(ys.back(), P + "transition3.3.0.0", P + "transition3.3.0.1", 2, 0, nullptr, nullptr, R));
+    ys = hr_stage(B, ys, 4, 3, 4, true);
+    TView logits = B.conv(ys[0], "unnormalized_model.1", "", 1, 0, nullptr, nullptr, 0, nullptr, true);
+    B.release(ys[0]);
+    return logits;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// YOLOv8 detect (ultralytics graph).  Concats are channel slices of one buffer: producers write
+// straight into their slice, consumers read slices; nothing is copied except the nearest-x2 upsample.
+// ------------------------------------------------------------------------------------------------------------
+struct YoloDims { int c[5]; int n[4]; };
+static YoloDims yolo_dims(int variant)
+{
+    static const double D[5] = {0.33, 0.33, 0.67, 1.0, 1.0}, Wd[5] = {0.25, 0.5, 0.75, 1.0, 1.25};
+    static const int MC[5] = {1024, 1024, 768, 512, 512};
+    YoloDims y;
+    const int base[5] = {64, 128, 256, 512, 1024};
+    for (int i = 0; i < 5; ++i) y.c[i] = (int)std::ceil(std::min(base[i], MC[variant]) * Wd[variant] / 8.0) * 8;
+    const int rep[4] = {3, 6, 6, 3};
+    for (int i = 0; i < 4; ++i) y.n[i] = std::max((int)std::nearbyint(rep[i] * D[variant]), 1);
+    return y;
+}
+
+struct YoloBuilder {
+    Builder& B;
+    int S = ACT_SILU;
+    TView cv(const TView& x, const std::string& name, int stride = 1, const TView* r1 = nullptr, const TView* out = nullptr)
+    {
+        return B.conv(x, name + ".conv", name + ".bn", stride, S, r1, nullptr, 0, out);
+    }
+    // C2f writing its result into `out` (or a fresh tensor)
+    TView c2f(const TView& x, int idx, int cout, int n, bool shortcut, const TView* out = nullptr)
+    {
+        const std::string p = "model." + std::to_string(idx);
+        const int c = cout / 2;
+        TView cat = B.act(x.h, x.w, (2 + n) * c);
+        TView first = cat.slice(0, 2 * c);
+        cv(x, p + ".cv1", 1, nullptr, &first);
+        for (int k = 0; k < n; ++k) {
+            TView in = cat.slice((1 + k) * c, c);
+            TView t = cv(in, p + ".m." + std::to_string(k) + ".cv1");
+            TView o = cat.slice((2 + k) * c, c);
+            cv(t, p + ".m." + std::to_string(k) + ".cv2", 1, shortcut ? &in : nullptr, &o);
+            B.release(t);
+        }
+        TView y = cv(cat, p + ".cv2", 1, nullptr, out);
+        B.release(cat);
+        return y;
+    }
+};
+
+static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3], int nc)
+{
+    YoloBuilder Y{B};
+    const YoloDims d = yolo_dims(variant);
+    const int c1 = d.c[0], c2 = d.c[1], c3 = d.c[2], c4 = d.c[3], c5 = d.c[4];
+    TView x0 = Y.cv(x_in, "model.0", 2);
+    TView x1 = Y.cv(x0, "model.1", 2); B.release(x0);
+    TView x2 = Y.c2f(x1, 2, c2, d.n[0], true); B.release(x1);
+    TView x3 = Y.cv(x2, "model.3", 2); B.release(x2);
+    const int h3 = x3.h, w3 = x3.w;                                   // stride 8
+    const int h4 = (h3 - 1) / 2 + 1, w4 = (w3 - 1) / 2 + 1, h5 = (h4 - 1) / 2 + 1, w5 = (w4 - 1) / 2 + 1;
+    // concat buffers of the head, allocated up-front so the backbone can write P3/P4/P5 into their slices
+    TView cat15 = B.act(h3, w3, c4 + c3);      // [up(h12) | p3]
+    TView cat12 = B.act(h4, w4, c5 + c4);      // [up(p5)  | p4]
+    TView cat18 = B.act(h4, w4, c3 + c4);      // [conv16  | h12]
+    TView cat21 = B.act(h5, w5, c4 + c5);      // [conv19  | p5]
+    TView p3 = cat15.slice(c4, c3), p4 = cat12.slice(c5, c4), p5 = cat21.slice(c4, c5), h12 = cat18.slice(c3, c4);
+    Y.c2f(x3, 4, c3, d.n[1], true, &p3); B.release(x3);
+    TView x5 = Y.cv(p3, "model.5", 2);
+    Y.c2f(x5, 6, c4, d.n[2], true, &p4); B.release(x5);
+    TView x7 = Y.cv(p4, "model.7", 2);
+    TView x8 = Y.c2f(x7, 8, c5, d.n[3], true); B.release(x7);
+    {   // SPPF
+        const int ch = c5 / 2;
+        TView cat = B.act(h5, w5, 4 * ch);
+        TView s0 = cat.slice(0, ch), s1 = cat.slice(ch, ch), s2 = cat.slice(2 * ch, ch), s3 = cat.slice(3 * ch, ch);
+        Y.cv(x8, "model.9.cv1", 1, nullptr, &s0); B.release(x8);
+        B.other([s0, s1](hipStream_t s) { maxpool5_launch(s0, s1, s); }, "maxpool");
+        B.other([s1, s2](hipStream_t s) { maxpool5_launch(s1, s2, s); }, "maxpool");
+        B.other([s2, s3](hipStream_t s) { maxpool5_launch(s2, s3, s); }, "maxpool");
+        Y.cv(cat, "model.9.cv2", 1, nullptr, &p5);
+        B.release(cat);
+    }
+    {
+        TView u = cat12.slice(0, c5);
+        B.other([p5, u](hipStream_t s) { upsample2_launch(p5, u, s); }, "up2");
+        Y.c2f(cat12, 12, c4, d.n[0], false, &h12);
+    }
+    TView h15;
+    {
+        TView u = cat15.slice(0, c4);
+        B.other([h12, u](hipStream_t s) { upsample2_launch(h12, u, s); }, "up2");
+        h15 = Y.c2f(cat15, 15, c3, d.n[0], false);
+    }
+    {
+        TView o = cat18.slice(0, c3);
+        Y.cv(h15, "model.16", 2, nullptr, &o);
+    }
+    TView h18 = Y.c2f(cat18, 18, c4, d.n[0], false);
+    {
+        TView o = cat21.slice(0, c4);
+        Y.cv(h18, "model.19", 2, nullptr, &o);
+    }
+    TView h21 = Y.c2f(cat21, 21, c5, d.n[0], false);
+    const TView feats[3] = {h15, h18, h21};
+    const float strides[3] = {8.f, 16.f, 32.f};
+    int a0 = 0;
+    for (int l = 0; l < 3; ++l) {
+        const std::string pb = "model.22.cv2." + std::to_string(l), pc = "model.22.cv3." + std::to_string(l);
+        TView b0 = Y.cv(feats[l], pb + ".0");
+        TView b1 = Y.cv(b0, pb + ".1"); B.release(b0);
+        TView box = B.conv(b1, pb + ".2", "", 1, 0, nullptr, nullptr, 0, nullptr, true); B.release(b1);
+        TView k0 = Y.cv(feats[l], pc + ".0");
+        TView k1 = Y.cv(k0, pc + ".1"); B.release(k0);
+        TView cls = B.conv(k1, pc + ".2", "", 1, 0, nullptr, nullptr, 0, nullptr, true); B.release(k1);
+        lv[l].box = box; lv[l].cls = cls; lv[l].gh = box.h; lv[l].gw = box.w; lv[l].stride = strides[l]; lv[l].a0 = a0;
+        a0 += box.h * box.w;
+    }
+    (void)c1; (void)nc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// step execution
+// ------------------------------------------------------------------------------------------------------------
+static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
+{
+    for (Op& op : net->ops) {
+        if (h->prof && op.kind == Op::CONV) {
+            HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], s));
+            op.run(s);
+            HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], s));
+        } else {
+            op.run(s);
+        }
+    }
+}
+
+// enqueue one batch step reading frames from d_src (device, dense [n,h,w,3])
+static void enqueue_step(EagleHandle* h, const uint8_t* d_src, int n_active)
+{
+    const EagleConfig& c = h->cfg;
+    const int B = c.batch;
+    size_t ev_i = 0;
+    HIP_CHECK(hipMemsetAsync(h->d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
+    TView kp = h->kp_in, det = h->det_in;
+    preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, kp, det, h->lb, h->s_main);
+    const bool two = h->s_det != h->s_main && !h->prof;
+    hipStream_t sd = two ? h->s_det : h->s_main;
+    if (two) {
+        HIP_CHECK(hipEventRecord(h->ev_pre, h->s_main));
+        HIP_CHECK(hipStreamWaitEvent(sd, h->ev_pre, 0));
+    }
+    // detector branch
+    run_net(h, h->yo.get(), sd, ev_i);
+    yolo_decode_launch(h->levels, 3, B, 5, c.detector_floor, h->ds, sd);
+    nms_launch(h->ds, B, h->pp, h->d_out, sd);
+    if (two) HIP_CHECK(hipEventRecord(h->ev_det, sd));
+    // keypoint branch
+    run_net(h, h->hr.get(), h->s_main, ev_i);
+    heat_argmax_launch(h->logits, h->d_parts, h->hm_chunks, h->s_main);
+    if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));
+    post_launch(h->d_parts, B, h->pp, h->d_out, h->s_main);
+}
+
+static void run_step(EagleHandle* h, const uint8_t* d_src, int n_active, EagleFrameResult* out)
+{
+    const EagleConfig& c = h->cfg;
+    HIP_CHECK(hipEventRecord(h->ev_t0, h->s_main));
+    if (c.use_graph && !h->prof) {
+        if (!h->warmed) {   // first call eager: lets every launcher set its function attributes outside a capture
+            enqueue_step(h, d_src, n_active);
+            HIP_CHECK(hipStreamSynchronize(h->s_main));
+            HIP_CHECK(hipStreamSynchronize(h->s_det));
+            h->warmed = true;
+        }
+        if (!h->gexec || h->g_src != d_src || h->g_n != n_active) {
+            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(h->s_main, hipStreamCaptureModeGlobal));
+            enqueue_step(h, d_src, n_active);
+            HIP_CHECK(hipStreamEndCapture(h->s_main, &g));
+            HIP_CHECK(hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            h->g_src = d_src; h->g_n = n_active;
+        }
+        HIP_CHECK(hipGraphLaunch(h->gexec, h->s_main));
+    } else {
+        enqueue_step(h, d_src, n_active);
+    }
+    HIP_CHECK(hipMemcpyAsync(h->h_out, h->d_out, sizeof(EagleFrameResult) * n_active, hipMemcpyDeviceToHost, h->s_main));
+    HIP_CHECK(hipEventRecord(h->ev_t1, h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    memcpy(out, h->h_out, sizeof(EagleFrameResult) * n_active);
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+    h->timings.total_ms += ms;
+    h->timings.n_launches += h->n_launch;
+    h->timings.n_conv_launches += h->n_conv;
+    h->timings.conv_flop += h->conv_flop_step;
+    if (h->prof) {
+        for (size_t i = 0; i + 1 < h->conv_ev.size(); i += 2) {
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, h->conv_ev[i], h->conv_ev[i + 1]));
+            h->timings.conv_ms += t;
+        }
+    }
+}
+
+static void finalize(EagleHandle* h)
+{
+    const EagleConfig& c = h->cfg;
+    const int B = c.batch;
+    h->prec = c.precision;
+    h->hr.reset(new Net); h->yo.reset(new Net); h->misc.reset(new Net);
+    const int cin_pad = h->prec == EAGLE_PREC_F16 ? 8 : 4;
+    h->lb = letterbox_geometry(c.frame_h, c.frame_w, c.det_imgsz);
+    // inputs (written by the preprocess kernel)
+    Builder Bh{h, h->hr.get(), h->prec, 1e-5, B};
+    Builder By{h, h->yo.get(), h->prec, 1e-3, B};
+    h->kp_in = Bh.act(540, 960, cin_pad);
+    h->det_in = By.act(h->lb.out_h, h->lb.out_w, cin_pad);
+    h->logits = build_hrnet(Bh, h->kp_in);
+    build_yolo(By, h->det_in, c.det_variant, h->levels, 5);
+    // scratch
+    Net* m = h->misc.get();
+    h->d_frames = (uint8_t*)m->get((size_t)B * c.frame_h * c.frame_w * 3);
+    h->d_parts = (ArgmaxPart*)m->get(sizeof(ArgmaxPart) * (size_t)B * h->hm_chunks * 64);
+    int A = 0;
+    for (int l = 0; l < 3; ++l) A += h->levels[l].gh * h->levels[l].gw;
+    h->ds.A = A;
+    h->ds.boxes = (float*)m->get(sizeof(float) * 4 * (size_t)B * A);
+    h->ds.conf = (float*)m->get(sizeof(float) * (size_t)B * A);
+    h->ds.cls = (int*)m->get(sizeof(int) * (size_t)B * A);
+    h->ds.keys = (unsigned long long*)m->get(sizeof(unsigned long long) * (size_t)B * A);
+    h->ds.count = (int*)m->get(sizeof(int) * (size_t)B);
+    h->d_out = (EagleFrameResult*)m->get(sizeof(EagleFrameResult) * (size_t)B);
+    HIP_CHECK(hipHostMalloc((void**)&h->h_out, sizeof(EagleFrameResult) * (size_t)B, hipHostMallocDefault));
+    PostParams& pp = h->pp;
+    pp.frame_h = c.frame_h; pp.frame_w = c.frame_w; pp.in_h = h->lb.out_h; pp.in_w = h->lb.out_w;
+    pp.hm_h = h->logits.h; pp.hm_w = h->logits.w; pp.hm_chunks = h->hm_chunks;
+    pp.keypoint_conf = c.keypoint_conf; pp.detector_conf = c.detector_conf; pp.nms_iou = c.nms_iou;
+    pp.ransac_thresh = c.ransac_thresh; pp.ransac_max_iters = c.ransac_max_iters; pp.lm_iters = c.lm_iters;
+    h->n_conv = 0; h->conv_flop_step = 0; h->n_launch = 6;
+    for (Net* n : {h->hr.get(), h->yo.get()})
+        for (Op& op : n->ops) { ++h->n_launch; if (op.kind == Op::CONV) { ++h->n_conv; h->conv_flop_step += op.flop; } }
+    h->conv_ev.resize((size_t)h->n_conv * 2);
+    for (auto& e : h->conv_ev) HIP_CHECK(hipEventCreate(&e));
+    h->weights.clear();      // host copies are no longer needed
+    h->finalized = true;
+}
+
+}  // namespace eagle
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+#define API_BEGIN try {
+#define API_END(h)                                                       \
+    }                                                                    \
+    catch (const eagle::Err& e) { if (h) (h)->err = e.msg; else eagle::g_create_error = e.msg; return e.code; } \
+    catch (const std::exception& e) { if (h) (h)->err = e.what(); else eagle::g_create_error = e.what(); return EAGLE_E_INVALID; } \
+    return EAGLE_OK;
+
+extern "C" {
+
+int eagle_abi_sizes(int32_t* o)
+{
+    if (!o) return EAGLE_E_INVALID;
+    o[0] = (int32_t)sizeof(EagleConfig); o[1] = (int32_t)sizeof(EagleFrameResult); o[2] = (int32_t)sizeof(EagleDet); o[3] = (int32_t)sizeof(EagleKeypoint);
+    return EAGLE_OK;
+}
+
+int eagle_default_config(EagleConfig* cfg)
+{
+    if (!cfg) return EAGLE_E_INVALID;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->device = 0; cfg->frame_h = 720; cfg->frame_w = 1280;
+    cfg->det_variant = EAGLE_DET_N; cfg->det_imgsz = 640; cfg->batch = 8; cfg->precision = EAGLE_PREC_F16;
+    cfg->keypoint_conf = 0.3; cfg->detector_conf = 0.35; cfg->ransac_thresh = 5.0;
+    cfg->detector_floor = 0.15f; cfg->nms_iou = 0.7f;
+    cfg->ransac_max_iters = 2000; cfg->lm_iters = 10; cfg->use_graph = 0;
+    return EAGLE_OK;
+}
+
+int eagle_create(const EagleConfig* cfg, EagleHandle** out)
+{
+    EagleHandle* h = nullptr;
+    API_BEGIN
+    if (!cfg || !out) fail(EAGLE_E_INVALID, "null argument");
+    if (cfg->batch < 1 || cfg->frame_h < 32 || cfg->frame_w < 32) fail(EAGLE_E_INVALID, "bad batch/frame size");
+    if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32) fail(EAGLE_E_INVALID, "bad precision");
+    if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) fail(EAGLE_E_HIP, "device %d not present (%d visible)", cfg->device, ndev);
+    HIP_CHECK(hipSetDevice(cfg->device));
+    EagleHandle* nh = new EagleHandle;
+    nh->cfg = *cfg;
+    HIP_CHECK(hipStreamCreateWithFlags(&nh->s_main, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&nh->s_det, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&nh->ev_pre, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&nh->ev_det, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreate(&nh->ev_t0));
+    HIP_CHECK(hipEventCreate(&nh->ev_t1));
+    *out = nh;
+    API_END(h)
+}
+
+void eagle_destroy(EagleHandle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (auto& e : h->conv_ev) (void)hipEventDestroy(e);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    h->hr.reset(); h->yo.reset(); h->misc.reset();
+    if (h->s_main) (void)hipStreamDestroy(h->s_main);
+    if (h->s_det) (void)hipStreamDestroy(h->s_det);
+    for (hipEvent_t e : {h->ev_pre, h->ev_det, h->ev_t0, h->ev_t1}) if (e) (void)hipEventDestroy(e);
+    delete h;
+}
+
+const char* eagle_last_error(EagleHandle* h) { return h ? h->err.c_str() : eagle::g_create_error.c_str(); }
+
+int eagle_load_weights(EagleHandle* h, const char* name, const float* data, const int64_t* shape, int ndim)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!name || !data || ndim < 0 || ndim > 8) fail(EAGLE_E_INVALID, "bad weight tensor");
+    if (h->finalized) fail(EAGLE_E_STATE, "weights already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    h->weights[name] = std::move(t);
+    API_END(h)
+}
+
+int eagle_finalize_weights(EagleHandle* h)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (h->finalized) fail(EAGLE_E_STATE, "already finalized");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    finalize(h);
+    API_END(h)
+}
+
+int eagle_process_device_frames(EagleHandle* h, const void* d_bgr, int n, EagleFrameResult* out)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!h->finalized) fail(EAGLE_E_STATE, "eagle_finalize_weights has not been called");
+    if (!d_bgr || !out || n < 0) fail(EAGLE_E_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    memset(&h->timings, 0, sizeof(h->timings));
+    const size_t fsz = (size_t)h->cfg.frame_h * h->cfg.frame_w * 3;
+    for (int i = 0; i < n; i += h->cfg.batch) {
+        const int na = std::min(h->cfg.batch, n - i);
+        run_step(h, (const uint8_t*)d_bgr + (size_t)i * fsz, na, out + i);
+    }
+    API_END(h)
+}
+
+int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t frame_stride, int64_t row_stride, EagleFrameResult* out)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!h->finalized) fail(EAGLE_E_STATE, "eagle_finalize_weights has not been called");
+    if (!bgr || !out || n < 0) fail(EAGLE_E_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    memset(&h->timings, 0, sizeof(h->timings));
+    const int fh = h->cfg.frame_h, fw = h->cfg.frame_w;
+    const size_t fsz = (size_t)fh * fw * 3;
+    if (row_stride == 0) row_stride = (int64_t)fw * 3;
+    if (frame_stride == 0) frame_stride = row_stride * fh;
+    for (int i = 0; i < n; i += h->cfg.batch) {
+        const int na = std::min(h->cfg.batch, n - i);
+        for (int k = 0; k < na; ++k)
+            HIP_CHECK(hipMemcpy2DAsync(h->d_frames + (size_t)k * fsz, (size_t)fw * 3, bgr + (size_t)(i + k) * frame_stride,
+                                       (size_t)row_stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, h->s_main));
+        run_step(h, h->d_frames, na, out + i);
+    }
+    API_END(h)
+}
+
+int eagle_device_alloc(EagleHandle* h, int64_t bytes, void** dptr)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    HIP_CHECK(hipMalloc(dptr, (size_t)bytes));
+    API_END(h)
+}
+int eagle_device_free(EagleHandle* h, void* dptr)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    HIP_CHECK(hipFree(dptr));
+    API_END(h)
+}
+int eagle_device_upload(EagleHandle* h, void* dptr, const void* src, int64_t bytes)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    HIP_CHECK(hipMemcpy(dptr, src, (size_t)bytes, hipMemcpyHostToDevice));
+    API_END(h)
+}
+
+int eagle_set_profiling(EagleHandle* h, int on)
+{
+    if (!h) return EAGLE_E_INVALID;
+    h->prof = on != 0;
+    return EAGLE_OK;
+}
+int eagle_get_timings(EagleHandle* h, EagleTimings* t)
+{
+    if (!h || !t) return EAGLE_E_INVALID;
+    *t = h->timings;
+    return EAGLE_OK;
+}
+
+// ---- RCCL gather (resolved lazily with dlopen so the library loads on hosts without RCCL) ------------------------
+typedef struct { char internal[128]; } nccl_uid;
+typedef int (*fn_uid)(nccl_uid*);
+typedef int (*fn_init)(void**, int, nccl_uid, int);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_destroy)(void*);
+typedef const char* (*fn_errstr)(int);
+
+static void* rccl_lib()
+{
+    static void* lib = nullptr;
+    if (!lib) {
+        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+    }
+    return lib;
+}
+
+int eagle_comm_id(void* id128)
+{
+    EagleHandle* h = nullptr;
+    API_BEGIN
+    void* lib = rccl_lib();
+    if (!lib) fail(EAGLE_E_COMM, "librccl not found: %s", dlerror());
+    fn_uid f = (fn_uid)dlsym(lib, "ncclGetUniqueId");
+    if (!f) fail(EAGLE_E_COMM, "ncclGetUniqueId missing");
+    nccl_uid id;
+    const int rc = f(&id);
+    if (rc) fail(EAGLE_E_COMM, "ncclGetUniqueId failed: %d", rc);
+    memcpy(id128, &id, 128);
+    API_END(h)
+}
+
+int eagle_comm_init(EagleHandle* h, int rank, int world, const void* id128)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    void* lib = rccl_lib();
+    if (!lib) fail(EAGLE_E_COMM, "librccl not found");
+    fn_init f = (fn_init)dlsym(lib, "ncclCommInitRank");
+    if (!f) fail(EAGLE_E_COMM, "ncclCommInitRank missing");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    nccl_uid id;
+    memcpy(&id, id128, 128);
+    const int rc = f(&h->comm, world, id, rank);
+    if (rc) fail(EAGLE_E_COMM, "ncclCommInitRank failed: %d", rc);
+    h->rank = rank; h->world = world; h->rccl = lib;
+    API_END(h)
+}
+
+int eagle_gather(EagleHandle* h, const EagleFrameResult* local, int n_local, EagleFrameResult* all)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!local || !all || n_local < 0) fail(EAGLE_E_INVALID, "bad argument");
+    const size_t bytes = sizeof(EagleFrameResult) * (size_t)n_local;
+    if (h->world == 1 && !h->comm) { memcpy(all, local, bytes); return EAGLE_OK; }
+    if (!h->comm) fail(EAGLE_E_STATE, "eagle_comm_init has not been called");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    fn_allgather ag = (fn_allgather)dlsym(h->rccl, "ncclAllGather");
+    if (!ag) fail(EAGLE_E_COMM, "ncclAllGather missing");
+    void *d_send = nullptr, *d_recv = nullptr;
+    HIP_CHECK(hipMalloc(&d_send, std::max<size_t>(bytes, 16)));
+    HIP_CHECK(hipMalloc(&d_recv, std::max<size_t>(bytes * h->world, 16)));
+    HIP_CHECK(hipMemcpyAsync(d_send, local, bytes, hipMemcpyHostToDevice, h->s_main));
+    const int rc = ag(d_send, d_recv, bytes, /*ncclChar*/ 0, h->comm, h->s_main);
+    if (rc) { (void)hipFree(d_send); (void)hipFree(d_recv); fail(EAGLE_E_COMM, "ncclAllGather failed: %d", rc); }
+    HIP_CHECK(hipMemcpyAsync(all, d_recv, bytes * h->world, hipMemcpyDeviceToHost, h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    (void)hipFree(d_send); (void)hipFree(d_recv);
+    API_END(h)
+}
+
+// ---- operator-level entry points for the parity tests ---------------------------------------------------------------
+static void to_dev(Net& net, int prec, const float* src, int n, int h, int w, int c, int cpad, TView& v)
+{
+    v.n = n; v.h = h; v.w = w; v.c = cpad; v.cs = cpad; v.off = 0; v.f32 = prec == EAGLE_PREC_F32;
+    const size_t px = (size_t)n * h * w;
+    if (v.f32) {
+        std::vector<float> t(px * cpad, 0.f);
+        for (size_t p = 0; p < px; ++p) for (int k = 0; k < c; ++k) t[p * cpad + k] = src[p * c + k];
+        v.p = net.upload(t.data(), t.size() * 4);
+    } else {
+        std::vector<_Float16> t(px * cpad, (_Float16)0.f);
+        for (size_t p = 0; p < px; ++p) for (int k = 0; k < c; ++k) t[p * cpad + k] = (_Float16)src[p * c + k];
+        v.p = net.upload(t.data(), t.size() * 2);
+    }
+}
+static void from_dev(const TView& v, int c, float* dst)
+{
+    const size_t px = (size_t)v.n * v.h * v.w;
+    if (v.f32) {
+        std::vector<float> t(px * v.cs);
+        HIP_CHECK(hipMemcpy(t.data(), v.p, t.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < px; ++p) for (int k = 0; k < c; ++k) dst[p * c + k] = t[p * v.cs + v.off + k];
+    } else {
+        std::vector<_Float16> t(px * v.cs);
+        HIP_CHECK(hipMemcpy(t.data(), v.p, t.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < px; ++p) for (int k = 0; k < c; ++k) dst[p * c + k] = (float)t[p * v.cs + v.off + k];
+    }
+}
+
+int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int w, int cin, const float* w_hwio,
+                    const float* bias, int cout, int ks, int stride, int pre_act, const float* r1, const float* r2,
+                    int post_act, float* y)
+{
+    EagleHandle* hh = nullptr;
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    Net net;
+    const int g = precision == EAGLE_PREC_F16 ? 8 : 4;
+    const int cin_pad = cin <= g ? g : (cin + 15) / 16 * 16, cout_pad = (cout + 15) / 16 * 16;
+    const int ho = (h + 2 * (ks / 2) - ks) / stride + 1, wo = (w + 2 * (ks / 2) - ks) / stride + 1;
+    ConvLaunch L;
+    to_dev(net, precision, x, n, h, w, cin, cin_pad, L.x);
+    L.cfg = conv_choose(precision, ks, stride, cin_pad, cout_pad, wo);
+    if (!conv_supported(precision, L.cfg)) fail(EAGLE_E_NOKERNEL, "no kernel instance ks=%d s=%d kc=%d nt=%d", ks, stride, L.cfg.kc, L.cfg.nt);
+    std::vector<char> tiled(conv_weight_elems(precision, L.cfg) * (precision == EAGLE_PREC_F16 ? 2 : 4));
+    conv_tile_weights(precision, L.cfg, w_hwio, cin, cout, tiled.data());
+    L.w = net.upload(tiled.data(), tiled.size());
+    std::vector<float> b(cout_pad, 0.f);
+    for (int i = 0; i < cout; ++i) b[i] = bias[i];
+    L.bias = (const float*)net.upload(b.data(), b.size() * 4);
+    L.y.n = n; L.y.h = ho; L.y.w = wo; L.y.c = cout_pad; L.y.cs = cout_pad; L.y.f32 = precision == EAGLE_PREC_F32;
+    L.y.p = net.get((size_t)n * ho * wo * cout_pad * L.y.esize());
+    if (r1) to_dev(net, precision, r1, n, ho, wo, cout, cout_pad, L.r1);
+    if (r2) to_dev(net, precision, r2, n, ho, wo, cout, cout_pad, L.r2);
+    L.pre_act = pre_act; L.post_act = post_act;
+    conv_launch(precision, L, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    from_dev(L.y, cout, y);
+    API_END(hh)
+}
+
+int eagle_op_fuse_sum(int device, int precision, const float* base, int n, int H, int W, int c, int n_up,
+                      const float* const* ups, const int* up_h, const int* up_w, int relu, float* y)
+{
+    EagleHandle* hh = nullptr;
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    if (n_up > 3 || c % 8) fail(EAGLE_E_INVALID, "fuse_sum: n_up <= 3 and c %% 8 == 0 required");
+    Net net;
+    TView b, o;
+    to_dev(net, precision, base, n, H, W, c, c, b);
+    FuseUp u[3];
+    for (int i = 0; i < n_up; ++i) to_dev(net, precision, ups[i], n, up_h[i], up_w[i], c, c, u[i].z);
+    o = b; o.p = net.get((size_t)n * H * W * c * b.esize());
+    fuse_sum_launch(b, u, n_up, relu, o, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    from_dev(o, c, y);
+    API_END(hh)
+}
+
+int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz,
+                        float* kp_out, float* det_out, int* det_hw)
+{
+    EagleHandle* hh = nullptr;
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    Net net;
+    const int cp = precision == EAGLE_PREC_F16 ? 8 : 4;
+    const LetterBox lb = letterbox_geometry(h, w, det_imgsz);
+    det_hw[0] = lb.out_h; det_hw[1] = lb.out_w;
+    if (!kp_out || !det_out) return EAGLE_OK;
+    uint8_t* d = (uint8_t*)net.upload(bgr, (size_t)n * h * w * 3);
+    TView kp, det;
+    kp.n = n; kp.h = 540; kp.w = 960; kp.c = kp.cs = cp; kp.f32 = precision == EAGLE_PREC_F32;
+    det = kp; det.h = lb.out_h; det.w = lb.out_w;
+    kp.p = net.get((size_t)n * 540 * 960 * cp * kp.esize());
+    det.p = net.get((size_t)n * lb.out_h * lb.out_w * cp * det.esize());
+    preprocess_launch(precision, d, n, h, w, kp, det, lb, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    from_dev(kp, 3, kp_out);
+    from_dev(det, 3, det_out);
+    API_END(hh)
+}
+
+int eagle_op_find_homography(int device, const float* img_pts, const float* world_pts, int n, double thresh,
+                             int max_iters, int lm_iters, double* H9, uint8_t* mask, int* ok)
+{
+    EagleHandle* hh = nullptr;
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    if (n < 0 || n > EAGLE_MAX_KP) fail(EAGLE_E_INVALID, "0 <= n <= %d required", EAGLE_MAX_KP);
+    Net net;
+    float* di = (float*)net.upload(img_pts, sizeof(float) * 2 * std::max(n, 1));
+    float* dw = (float*)net.upload(world_pts, sizeof(float) * 2 * std::max(n, 1));
+    double* dH = (double*)net.get(72);
+    uint8_t* dm = (uint8_t*)net.get(256);
+    int* dok = (int*)net.get(16);
+    homography_only_launch(di, dw, n, thresh, max_iters, lm_iters, dH, dm, dok, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(H9, dH, 72, hipMemcpyDeviceToHost));
+    if (n > 0) HIP_CHECK(hipMemcpy(mask, dm, n, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(ok, dok, sizeof(int), hipMemcpyDeviceToHost));
+    API_END(hh)
+}
+
+}  // extern "C"

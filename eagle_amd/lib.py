@@ -1,0 +1,268 @@
+"""ctypes binding of ``libeagle_hip.so`` (C ABI: ``include/eagle.h``).
+
+There is deliberately **no fallback**: if the shared library is missing or a call fails, an exception is raised.
+torch is not imported here — the library talks to HIP directly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeagle_hip.so")
+
+MAX_DET, N_LANDMARKS, MAX_KP = 300, 57, 87
+PREC_F16, PREC_F32 = 0, 1
+DET_VARIANTS = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
+
+
+class EagleError(RuntimeError):
+    pass
+
+
+class EagleConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("frame_h", C.c_int32), ("frame_w", C.c_int32), ("det_variant", C.c_int32),
+                ("det_imgsz", C.c_int32), ("batch", C.c_int32), ("precision", C.c_int32),
+                ("keypoint_conf", C.c_double), ("detector_conf", C.c_double), ("ransac_thresh", C.c_double),
+                ("detector_floor", C.c_float), ("nms_iou", C.c_float),
+                ("ransac_max_iters", C.c_int32), ("lm_iters", C.c_int32), ("use_graph", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+class EagleTimings(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("conv_ms", C.c_float), ("n_launches", C.c_int32),
+                ("n_conv_launches", C.c_int32), ("conv_flop", C.c_double), ("reserved", C.c_int32 * 8)]
+
+
+# numpy mirrors of the record structs (C layout, natural alignment — checked against sizeof in tests)
+DET_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("conf", "<f4"), ("cls", "<i4"),
+                      ("id", "<i4"), ("bx1", "<i4"), ("by1", "<i4"), ("bx2", "<i4"), ("by2", "<i4"),
+                      ("foot_x", "<i4"), ("foot_y", "<i4"), ("pitch_xf", "<f4"), ("pitch_yf", "<f4"),
+                      ("pitch_x", "<i4"), ("pitch_y", "<i4"), ("reported", "u1"), ("in_bounds", "u1"), ("pad", "u1", 2)],
+                     align=True)
+KP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4"), ("synthesized", "u1"),
+                     ("on_plane", "u1"), ("inlier", "u1"), ("pad", "u1")], align=True)
+RESULT_DTYPE = np.dtype([("n_det", "<i4"), ("n_kp", "<i4"), ("n_candidates", "<i4"), ("H_valid", "u1"),
+                         ("bounds_valid", "u1"), ("pad", "u1", 2), ("H", "<f8", 9), ("bounds", "<f8", 4),
+                         ("hm_idx", "<i4", N_LANDMARKS), ("hm_score", "<f4", N_LANDMARKS),
+                         ("kp", KP_DTYPE, MAX_KP), ("det", DET_DTYPE, MAX_DET)], align=True)
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare the prototypes.  Raises EagleError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EagleError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback for the product path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    fp, dp, u8p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    L.eagle_abi_sizes.argtypes = [C.POINTER(C.c_int32)]
+    L.eagle_default_config.argtypes = [C.POINTER(EagleConfig)]
+    L.eagle_create.argtypes = [C.POINTER(EagleConfig), C.POINTER(vp)]
+    L.eagle_destroy.argtypes = [vp]
+    L.eagle_destroy.restype = None
+    L.eagle_last_error.argtypes = [vp]
+    L.eagle_last_error.restype = C.c_char_p
+    L.eagle_load_weights.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
+    L.eagle_finalize_weights.argtypes = [vp]
+    L.eagle_process_frames.argtypes = [vp, u8p, i32, i64, i64, vp]
+    L.eagle_process_device_frames.argtypes = [vp, vp, i32, vp]
+    L.eagle_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+    L.eagle_device_free.argtypes = [vp, vp]
+    L.eagle_device_upload.argtypes = [vp, vp, vp, i64]
+    L.eagle_comm_id.argtypes = [vp]
+    L.eagle_comm_init.argtypes = [vp, i32, i32, vp]
+    L.eagle_gather.argtypes = [vp, vp, i32, vp]
+    L.eagle_set_profiling.argtypes = [vp, i32]
+    L.eagle_get_timings.argtypes = [vp, C.POINTER(EagleTimings)]
+    L.eagle_op_conv2d.argtypes = [i32, i32, fp, i32, i32, i32, i32, fp, fp, i32, i32, i32, i32, fp, fp, i32, fp]
+    L.eagle_op_fuse_sum.argtypes = [i32, i32, fp, i32, i32, i32, i32, i32, C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, fp]
+    L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
+    L.eagle_op_find_homography.argtypes = [i32, fp, fp, i32, C.c_double, i32, i32, dp, u8p, C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_destroy", "eagle_last_error", "eagle_load_weights",
+           "eagle_finalize_weights", "eagle_process_frames", "eagle_process_device_frames", "eagle_device_alloc",
+           "eagle_device_free", "eagle_device_upload", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
+           "eagle_set_profiling", "eagle_get_timings", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
+           "eagle_op_find_homography"]
+
+
+def abi_sizes():
+    o = (C.c_int32 * 4)()
+    load().eagle_abi_sizes(o)
+    return list(o)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def default_config(**kw):
+    cfg = EagleConfig()
+    load().eagle_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if k == "det_variant" and isinstance(v, str):
+            v = DET_VARIANTS[v]
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown config field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Handle:
+    """One library handle == one GPU worker (not thread-safe)."""
+
+    def __init__(self, cfg=None, **kw):
+        self.L = load()
+        self.cfg = cfg or default_config(**kw)
+        self._h = C.c_void_p()
+        rc = self.L.eagle_create(C.byref(self.cfg), C.byref(self._h))
+        if rc:
+            raise EagleError(f"eagle_create failed ({rc}): {self.L.eagle_last_error(None).decode()}")
+
+    def _check(self, rc, what):
+        if rc:
+            raise EagleError(f"{what} failed ({rc}): {self.L.eagle_last_error(self._h).decode()}")
+
+    def close(self):
+        if self._h:
+            self.L.eagle_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weight(self, name, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+        self._check(self.L.eagle_load_weights(self._h, name.encode(), _fp(arr), shape, arr.ndim), f"load_weights({name})")
+
+    def finalize_weights(self):
+        self._check(self.L.eagle_finalize_weights(self._h), "finalize_weights")
+
+    def process(self, frames):
+        """frames: uint8 [n,h,w,3] BGR (host).  -> structured array [n] of RESULT_DTYPE."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if frames.ndim == 3:
+            frames = frames[None]
+        n, h, w, c = frames.shape
+        if (h, w, c) != (self.cfg.frame_h, self.cfg.frame_w, 3):
+            raise EagleError(f"frame shape {(h, w, c)} does not match the handle ({self.cfg.frame_h}, {self.cfg.frame_w}, 3)")
+        out = np.zeros(n, RESULT_DTYPE)
+        self._check(self.L.eagle_process_frames(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, 0, 0,
+                                                out.ctypes.data_as(C.c_void_p)), "process_frames")
+        return out
+
+    def upload(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        d = C.c_void_p()
+        self._check(self.L.eagle_device_alloc(self._h, frames.nbytes, C.byref(d)), "device_alloc")
+        self._check(self.L.eagle_device_upload(self._h, d, frames.ctypes.data_as(C.c_void_p), frames.nbytes), "device_upload")
+        return d
+
+    def free(self, d):
+        self._check(self.L.eagle_device_free(self._h, d), "device_free")
+
+    def process_device(self, dptr, n, out=None):
+        if out is None:
+            out = np.zeros(n, RESULT_DTYPE)
+        self._check(self.L.eagle_process_device_frames(self._h, dptr, n, out.ctypes.data_as(C.c_void_p)), "process_device_frames")
+        return out
+
+    def set_profiling(self, on):
+        self._check(self.L.eagle_set_profiling(self._h, int(on)), "set_profiling")
+
+    def timings(self):
+        t = EagleTimings()
+        self._check(self.L.eagle_get_timings(self._h, C.byref(t)), "get_timings")
+        return t
+
+    # --- multi-GPU -------------------------------------------------------------------------------------
+    def comm_init(self, rank, world, uid_bytes):
+        buf = C.create_string_buffer(bytes(uid_bytes), 128)
+        self._check(self.L.eagle_comm_init(self._h, rank, world, buf), "comm_init")
+
+    def gather(self, local, world):
+        local = np.ascontiguousarray(local)
+        out = np.zeros(len(local) * world, RESULT_DTYPE)
+        self._check(self.L.eagle_gather(self._h, local.ctypes.data_as(C.c_void_p), len(local), out.ctypes.data_as(C.c_void_p)), "gather")
+        return out
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = load().eagle_comm_id(buf)
+    if rc:
+        raise EagleError(f"eagle_comm_id failed ({rc}): {load().eagle_last_error(None).decode()}")
+    return buf.raw
+
+
+# --- operator-level wrappers (parity tests) -------------------------------------------------------------------
+def op_conv2d(x, w_hwio, bias, stride=1, pre=0, r1=None, r2=None, post=0, precision=PREC_F32, device=0):
+    L = load()
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w_hwio, np.float32); b = np.ascontiguousarray(bias, np.float32)
+    n, h, wd, cin = x.shape
+    ks, _, _, cout = w.shape
+    ho = (h + 2 * (ks // 2) - ks) // stride + 1
+    wo = (wd + 2 * (ks // 2) - ks) // stride + 1
+    y = np.empty((n, ho, wo, cout), np.float32)
+    r1 = None if r1 is None else np.ascontiguousarray(r1, np.float32)
+    r2 = None if r2 is None else np.ascontiguousarray(r2, np.float32)
+    rc = L.eagle_op_conv2d(device, precision, _fp(x), n, h, wd, cin, _fp(w), _fp(b), cout, ks, stride, pre, _fp(r1), _fp(r2), post, _fp(y))
+    if rc:
+        raise EagleError(f"eagle_op_conv2d failed ({rc}): {L.eagle_last_error(None).decode()}")
+    return y
+
+
+def op_fuse_sum(base, ups, relu=True, precision=PREC_F32, device=0):
+    L = load()
+    base = np.ascontiguousarray(base, np.float32)
+    n, H, W, c = base.shape
+    ups = [np.ascontiguousarray(u, np.float32) for u in ups]
+    arr = (C.POINTER(C.c_float) * max(len(ups), 1))(*[_fp(u) for u in ups])
+    uh = (C.c_int * max(len(ups), 1))(*[u.shape[1] for u in ups])
+    uw = (C.c_int * max(len(ups), 1))(*[u.shape[2] for u in ups])
+    y = np.empty_like(base)
+    rc = L.eagle_op_fuse_sum(device, precision, _fp(base), n, H, W, c, len(ups), arr, uh, uw, int(relu), _fp(y))
+    if rc:
+        raise EagleError(f"eagle_op_fuse_sum failed ({rc}): {L.eagle_last_error(None).decode()}")
+    return y
+
+
+def op_preprocess(frames, det_imgsz=640, precision=PREC_F32, device=0):
+    L = load()
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w, _ = frames.shape
+    hw = (C.c_int * 2)()
+    rc = L.eagle_op_preprocess(device, precision, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, h, w, det_imgsz, None, None, hw)
+    if rc:
+        raise EagleError(f"eagle_op_preprocess failed ({rc}): {L.eagle_last_error(None).decode()}")
+    kp = np.empty((n, 540, 960, 3), np.float32)
+    det = np.empty((n, hw[0], hw[1], 3), np.float32)
+    rc = L.eagle_op_preprocess(device, precision, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, h, w, det_imgsz, _fp(kp), _fp(det), hw)
+    if rc:
+        raise EagleError(f"eagle_op_preprocess failed ({rc}): {L.eagle_last_error(None).decode()}")
+    return kp, det
+
+
+def op_find_homography(img_pts, world_pts, thresh=5.0, max_iters=2000, lm_iters=10, device=0):
+    L = load()
+    a = np.ascontiguousarray(img_pts, np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(world_pts, np.float32).reshape(-1, 2)
+    n = len(a)
+    H = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8); ok = C.c_int(0)
+    rc = L.eagle_op_find_homography(device, _fp(a), _fp(b), n, thresh, max_iters, lm_iters,
+                                    H.ctypes.data_as(C.POINTER(C.c_double)), mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(ok))
+    if rc:
+        raise EagleError(f"eagle_op_find_homography failed ({rc}): {L.eagle_last_error(None).decode()}")
+    return (H.reshape(3, 3), mask[:n]) if ok.value else (None, None)

@@ -1,0 +1,166 @@
+/*
+ * eagle.h — C ABI of the MI355X-native per-frame inference path for nreHieW/Eagle.
+ *
+ * The reference has no plugin / FFI interface: the path is reached through three Python call
+ * sites of eagle/models/coordinate_model.py, which are the seams this library replaces:
+ *   (1) detector      self.detector_model(frame, verbose=False, conf=low_conf)[0].boxes   cm.py:568-572
+ *   (2) keypoints     self.keypoint_model.get_keypoints(batch)                            cm.py:226,253,492
+ *                                                                                         kh.py:575-595
+ *   (3) homography    cv2.findHomography / cv2.perspectiveTransform                       cm.py:355,383,400-403
+ * and the per-frame loop body that strings them together (cm.py:277-415) in the stateless configuration
+ * (keypoint_interval = homography_interval = 1, tracker off: IDs = detection index, cm.py:598-627).
+ *
+ * Conventions: every function returns 0 on success or a negative EAGLE_E_* code and never throws; the caller
+ * owns the `bgr` and `out` host buffers; the library owns all device memory and streams; one handle per
+ * (process, GPU); a handle is not thread-safe; different handles are independent.
+ * Plain pointers and sizes only — no torch / numpy types cross this boundary.
+ */
+#ifndef EAGLE_H
+#define EAGLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAGLE_OK 0
+#define EAGLE_E_INVALID (-1)   /* bad argument */
+#define EAGLE_E_HIP (-2)       /* HIP runtime error (see eagle_last_error) */
+#define EAGLE_E_STATE (-3)     /* call order: weights not finalized, etc. */
+#define EAGLE_E_MISSING (-4)   /* a required weight tensor was never loaded */
+#define EAGLE_E_NOKERNEL (-5)  /* no kernel instance for a layer shape */
+#define EAGLE_E_COMM (-6)      /* RCCL error */
+
+#define EAGLE_MAX_DET 300      /* ultralytics max_det */
+#define EAGLE_N_LANDMARKS 57   /* eagle/utils/pitch.py:1-60 */
+#define EAGLE_MAX_KP 87        /* 57 detected + at most 30 synthesised (cm.py:140) */
+
+#define EAGLE_PREC_F16 0       /* fp16 tensors, fp32 accumulate on v_mfma_f32_16x16x32_f16 (fast path) */
+#define EAGLE_PREC_F32 1       /* fp32 tensors on v_mfma_f32_16x16x4_f32: bit-exact vs the oracle's fmaf chain */
+
+#define EAGLE_DET_N 0
+#define EAGLE_DET_S 1
+#define EAGLE_DET_M 2
+#define EAGLE_DET_L 3
+#define EAGLE_DET_X 4
+
+typedef struct EagleHandle EagleHandle;
+
+/* Replaces the constructor arguments of CoordinateModel (cm.py:49-74) and the constants of cm.py:18-20,567. */
+typedef struct EagleConfig {
+    int32_t device;            /* HIP device ordinal */
+    int32_t frame_h, frame_w;  /* e.g. 720, 1280 */
+    int32_t det_variant;       /* EAGLE_DET_* */
+    int32_t det_imgsz;         /* 640 (detector_medium/large) or 960 (detector_large_hd), README.md:107-111 */
+    int32_t batch;             /* frames processed per device step (>= 1) */
+    int32_t precision;         /* EAGLE_PREC_* */
+    double keypoint_conf;      /* 0.3   cm.py:49  (double: the reference compares Python floats) */
+    double detector_conf;      /* 0.35  cm.py:49 */
+    double ransac_thresh;      /* 5.0   cm.py:355 */
+    float detector_floor;      /* 0.15  cm.py:567 (compared in fp32 by ultralytics) */
+    float nms_iou;             /* 0.7   ultralytics default */
+    int32_t ransac_max_iters;  /* 2000  cv2 default */
+    int32_t lm_iters;          /* 10    cv2 default */
+    int32_t use_graph;         /* 1: capture the per-batch step into a hipGraph and replay it */
+    int32_t reserved[7];
+} EagleConfig;
+
+typedef struct EagleDet {      /* one row of boxes.xyxy/.conf/.cls after NMS (cm.py:569-572) + cm.py:598-627 */
+    float x1, y1, x2, y2;      /* float boxes in frame pixels, descending-confidence order */
+    float conf;
+    int32_t cls;               /* 0 Player 1 Goalkeeper 2 Ball 3 Referee 4 Staff (cm.py:61) */
+    int32_t id;                /* Player/Goalkeeper: detection index; Ball: enumerate index; -1 otherwise */
+    int32_t bx1, by1, bx2, by2;/* "BBox" ints (truncated, clipped for persons) */
+    int32_t foot_x, foot_y;    /* "Bottom_center" */
+    float pitch_xf, pitch_yf;  /* perspectiveTransform output before .astype(int) */
+    int32_t pitch_x, pitch_y;  /* "Transformed_Coordinates" (valid iff in_bounds) */
+    uint8_t reported;          /* 1: appears in the reference dict (class kept and conf >= detector_conf) */
+    uint8_t in_bounds;         /* 1: H valid and 0<=X<=105, 0<=Y<=68 */
+    uint8_t pad[2];
+} EagleDet;
+
+typedef struct EagleKeypoint {
+    int32_t label;             /* heat-map index 0..56 (label string via eagle/utils/pitch.py:1-60) */
+    int32_t x, y;              /* image pixels */
+    float score;               /* sigmoid maximum; 0 for synthesised points */
+    uint8_t synthesized;       /* 1: added by the line-intersection synthesis (cm.py:140-186) */
+    uint8_t on_plane;          /* 1: handed to findHomography (cm.py:338-347) */
+    uint8_t inlier;            /* 1: RANSAC inlier (cm.py:359-362); "Keypoints" = inliers when H_valid */
+    uint8_t pad;
+} EagleKeypoint;
+
+/* Fixed-size per-frame record == res[i] of cm.py:415 (schema docs/data.md:20-41). */
+typedef struct EagleFrameResult {
+    int32_t n_det;
+    int32_t n_kp;
+    int32_t n_candidates;      /* boxes above detector_floor before NMS */
+    uint8_t H_valid;
+    uint8_t bounds_valid;
+    uint8_t pad[2];
+    double H[9];               /* row-major, h33 = 1 */
+    double bounds[4];          /* x of [bottom_left(y=0), top_left(68), top_right(68), bottom_right(0)] */
+    int32_t hm_idx[EAGLE_N_LANDMARKS];   /* first-maximum flat index per heat-map (kh.py:588) */
+    float hm_score[EAGLE_N_LANDMARKS];   /* kh.py:589 */
+    EagleKeypoint kp[EAGLE_MAX_KP];
+    EagleDet det[EAGLE_MAX_DET];
+} EagleFrameResult;
+
+/* sizeof(EagleConfig), sizeof(EagleFrameResult), sizeof(EagleDet), sizeof(EagleKeypoint): binding self-check */
+int eagle_abi_sizes(int32_t* out4);
+int eagle_default_config(EagleConfig* cfg);
+int eagle_create(const EagleConfig* cfg, EagleHandle** out);
+void eagle_destroy(EagleHandle* h);
+const char* eagle_last_error(EagleHandle* h);   /* h may be NULL: last error of eagle_create */
+
+/* Weights: state-dict tensors by their reference names, fp32, PyTorch layouts
+ *   HRNet + head: "unnormalized_model.0.<...>", "unnormalized_model.1.{weight,bias}" (kh.py:559-562)
+ *   detector:     ultralytics "model.<N>.<...>"                                       (cm.py:54-57)
+ * eagle_finalize_weights folds BatchNorm, re-tiles for MFMA and builds the per-batch launch schedule. */
+int eagle_load_weights(EagleHandle* h, const char* name, const float* data, const int64_t* shape, int ndim);
+int eagle_finalize_weights(EagleHandle* h);
+
+/* The hot path: n BGR uint8 HWC frames (host memory, row stride in bytes) -> n records. */
+int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t frame_stride, int64_t row_stride,
+                         EagleFrameResult* out);
+
+/* Same, inputs already resident in HBM (device pointer, dense [n,h,w,3]); records still land on the host.
+ * This is the entry bench.py times ("inputs resident in HBM when the timed region starts"). */
+int eagle_process_device_frames(EagleHandle* h, const void* d_bgr, int n, EagleFrameResult* out);
+int eagle_device_alloc(EagleHandle* h, int64_t bytes, void** dptr);
+int eagle_device_free(EagleHandle* h, void* dptr);
+int eagle_device_upload(EagleHandle* h, void* dptr, const void* src, int64_t bytes);
+
+/* Frame-sharded multi-GPU: rank r owns a contiguous chunk; one RCCL all-gather of records.
+ * eagle_comm_id fills a 128-byte ncclUniqueId on rank 0; the caller broadcasts it (any channel). */
+int eagle_comm_id(void* id128);
+int eagle_comm_init(EagleHandle* h, int rank, int world, const void* id128);
+int eagle_gather(EagleHandle* h, const EagleFrameResult* local, int n_local, EagleFrameResult* all /* world*n_local */);
+
+/* Timing of the last eagle_process_* call, measured with HIP events on the library's compute stream. */
+typedef struct EagleTimings {
+    float total_ms;            /* first kernel -> records copied */
+    float conv_ms;             /* sum over convolution launches (only when profiling is enabled) */
+    int32_t n_launches;
+    int32_t n_conv_launches;
+    double conv_flop;          /* algorithmic FLOP of the convolutions of the last call (2*MAC) */
+    int32_t reserved[8];
+} EagleTimings;
+int eagle_set_profiling(EagleHandle* h, int per_kernel_events);
+int eagle_get_timings(EagleHandle* h, EagleTimings* t);
+
+/* Operator-level entry points (host buffers in/out) used by the parity tests: each runs ONE kernel of the path.
+ * Tensors are dense NHWC fp32 on the host; `precision` selects the fp16 or fp32 kernel family. */
+int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int w, int cin, const float* w_hwio,
+                    const float* bias, int cout, int ks, int stride, int pre_act, const float* r1, const float* r2,
+                    int post_act, float* y);
+int eagle_op_fuse_sum(int device, int precision, const float* base, int n, int H, int W, int c, int n_up,
+                      const float* const* ups, const int* up_h, const int* up_w, int relu, float* y);
+int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz,
+                        float* kp_out /* n*540*960*3 */, float* det_out /* n*dh*dw*3 */, int* det_hw /* 2 */);
+int eagle_op_find_homography(int device, const float* img_pts, const float* world_pts, int n, double thresh,
+                             int max_iters, int lm_iters, double* H9, uint8_t* mask, int* ok);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

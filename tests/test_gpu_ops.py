@@ -1,0 +1,120 @@
+"""-m gpu: each HIP kernel of the path against the CPU oracle, through the C ABI's operator entry points.
+fp32 kernels must be BIT-EXACT (same fmaf chain as oracle/eo_prims.c); fp16 kernels within the stated tolerance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F16_TOL = 2e-3  # relative to max|y|: fp16 output rounding (2^-11) + reordered fp32 accumulation
+
+
+def _rand(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, ks, stride, pre, post, r1, r2
+    (1, 20, 37, 48, 48, 3, 1, 0, 1, False, False),     # HRNet branch-0 shape, ragged tile edges
+    (2, 17, 30, 96, 96, 3, 1, 0, 1, True, False),      # BasicBlock conv2 with residual
+    (1, 33, 61, 48, 96, 3, 2, 0, 1, True, True),       # fuse downsample with running sum + identity
+    (1, 9, 13, 192, 384, 3, 2, 0, 0, False, False),
+    (1, 19, 23, 64, 256, 1, 1, 0, 1, True, False),     # Bottleneck conv3
+    (1, 16, 16, 384, 48, 1, 1, 0, 0, False, False),    # fuse 1x1
+    (1, 45, 52, 3, 64, 3, 2, 0, 1, False, False),      # stem
+    (1, 30, 41, 48, 57, 3, 1, 0, 0, False, False),     # head (57 real channels)
+    (1, 24, 40, 16, 16, 3, 1, 2, 0, True, False),      # YOLO bottleneck: x + silu(conv)
+    (1, 12, 20, 256, 128, 1, 1, 2, 0, False, False),   # YOLO 1x1 + SiLU
+    (1, 12, 20, 64, 5, 1, 1, 0, 0, False, False),      # class head
+    (3, 1, 1, 16, 16, 3, 1, 0, 0, False, False),       # degenerate 1x1 map, batch 3
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_conv_parity(case, prec):
+    from eagle_amd import lib
+    from oracle import prims as P
+    n, h, w, cin, cout, ks, st, pre, post, use_r1, use_r2 = case
+    x = _rand((n, h, w, cin), 1)
+    wt = _rand((ks, ks, cin, cout), 2, (2.0 / (cin * ks * ks)) ** 0.5)
+    b = _rand((cout,), 3, 0.1)
+    ho = (h + 2 * (ks // 2) - ks) // st + 1
+    wo = (w + 2 * (ks // 2) - ks) // st + 1
+    r1 = _rand((n, ho, wo, cout), 4) if use_r1 else None
+    r2 = _rand((n, ho, wo, cout), 5) if use_r2 else None
+    if prec == "f32":
+        ref = P.conv2d(x, wt, b, stride=st, pre=pre, r1=r1, r2=r2, post=post)
+        got = lib.op_conv2d(x, wt, b, st, pre, r1, r2, post, lib.PREC_F32)
+        assert np.array_equal(ref, got), f"fp32 conv not bit-exact: max|d|={np.abs(ref - got).max()}"
+    else:
+        q = P.round_f16
+        ref = P.conv2d(q(x), q(wt), b, stride=st, pre=pre, r1=None if r1 is None else q(r1),
+                       r2=None if r2 is None else q(r2), post=post, f16_out=True)
+        got = lib.op_conv2d(x, wt, b, st, pre, r1, r2, post, lib.PREC_F16)
+        err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+        assert err < F16_TOL, f"fp16 conv error {err}"
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_fuse_sum_parity(prec):
+    from eagle_amd import lib
+    from oracle import prims as P
+    base = _rand((2, 27, 31, 48), 1)
+    ups = [_rand((2, 14, 16, 48), 2), _rand((2, 7, 8, 48), 3), _rand((2, 4, 4, 48), 4)]
+    q = P.round_f16 if prec == "f16" else (lambda a: a)
+    y = q(base)
+    for u in ups:
+        y = y + P.upsample_bilinear_ac(q(u), 27, 31)
+    ref = np.maximum(y, np.float32(0))
+    got = lib.op_fuse_sum(base, ups, True, lib.PREC_F32 if prec == "f32" else lib.PREC_F16)
+    if prec == "f32":
+        assert np.array_equal(ref, got)
+    else:
+        assert np.array_equal(P.round_f16(ref), got)    # identical fp32 math, one fp16 rounding at the store
+
+
+@pytest.mark.parametrize("hw", [(720, 1280), (1080, 1920), (360, 640)])
+def test_preprocess_parity(hw):
+    from eagle_amd import lib, synth
+    from oracle import host
+    f = np.stack([synth.noise_frame(3, *hw), synth.frame(1, 4, *hw)])
+    kp, det = lib.op_preprocess(f, 640, lib.PREC_F32)
+    for i in range(2):
+        assert np.array_equal(host.preprocess_keypoints(f[i])[0], kp[i])
+        assert np.array_equal(host.preprocess_detector(f[i], 640)[0][0], det[i])
+
+
+def _camera_points(seed, noise=0.0, n_out=0):
+    from eagle_amd import synth
+    from eagle_amd.pitch import LANDMARKS, on_plane_mask
+    rng = np.random.default_rng(seed)
+    Hm = synth.camera(seed, 10 * seed)
+    m = on_plane_mask()
+    world = np.array([[x, y] for (i, _, x, y, z) in LANDMARKS if m[i]], np.float64)
+    img = synth.project(Hm, world)
+    keep = (img[:, 0] >= 0) & (img[:, 0] < 1280) & (img[:, 1] >= 0) & (img[:, 1] < 720)
+    img, world = img[keep], world[keep]
+    img = np.floor(img + rng.normal(0, noise, img.shape))
+    for k in rng.choice(len(img), size=min(n_out, len(img)), replace=False):
+        img[k] = rng.uniform(0, 700, 2)
+    return img.astype(np.float32), world.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,noise,n_out", [(0, 0.0, 0), (1, 0.7, 0), (2, 0.5, 4), (3, 1.0, 7), (4, 0.0, 2)])
+def test_find_homography_bit_exact(seed, noise, n_out):
+    from eagle_amd import lib
+    from oracle import prims as P
+    img, world = _camera_points(seed, noise, n_out)
+    H0, m0 = P.find_homography_ransac(img, world, 5.0)
+    H1, m1 = lib.op_find_homography(img, world, 5.0)
+    assert (H0 is None) == (H1 is None)
+    if H0 is not None:
+        assert np.array_equal(m0, m1)
+        assert np.array_equal(H0, H1), f"H differs: {np.abs(H0 - H1).max()}"
+
+
+def test_find_homography_degenerate():
+    from eagle_amd import lib
+    pts = np.array([[0, 0], [1, 1], [2, 2], [3, 3], [4, 4]], np.float32)
+    assert lib.op_find_homography(pts, pts)[0] is None          # collinear: no valid subset
+    assert lib.op_find_homography(pts[:3], pts[:3])[0] is None  # fewer than 4 points

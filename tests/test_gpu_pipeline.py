@@ -1,0 +1,95 @@
+"""-m gpu: the whole per-frame path through the C ABI against the CPU oracle on the same seeded frames/weights.
+
+fp32 handle: every integer (heat-map indices, keypoint pixels, NMS order/IDs, boxes, pitch ints) and H must be
+IDENTICAL to the oracle (scores/floats bit-equal too: same fmaf chains, same exp polynomial).
+fp16 handle (the fast path): heat-map maxima compared with near-tie handling, boxes by IoU, H by reprojection."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames():
+    from eagle_amd import synth
+    return np.stack([synth.frame(0, 0), synth.frame(0, 37), synth.noise_frame(1)])
+
+
+@pytest.fixture(scope="module")
+def oracle_steps(state_dicts, frames):
+    from oracle import pipeline
+    hs, ys = state_dicts
+    m = pipeline.OracleModel(hs, ys, backend="c")
+    return [m.step(f, i) for i, f in enumerate(frames)]
+
+
+def _canon(d):
+    """dict -> comparable plain structure (tuples -> lists, numpy scalars -> python)."""
+    if isinstance(d, dict):
+        return {str(k): _canon(v) for k, v in d.items() if not str(k).startswith("_")}
+    if isinstance(d, (list, tuple)):
+        return [_canon(v) for v in d]
+    if isinstance(d, (np.integer,)):
+        return int(d)
+    if isinstance(d, (np.floating,)):
+        return float(d)
+    return d
+
+
+def test_f32_path_identical_to_oracle(state_dicts, frames, oracle_steps):
+    from eagle_amd import records
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    cm = CoordinateModel(precision="f32", batch=2, hrnet_state_dict=hs, detector_state_dict=ys)
+    recs = cm.process_records(frames)          # 3 frames with batch 2: exercises the ragged last batch
+    for i, (rec, (oref, aux)) in enumerate(zip(recs, oracle_steps)):
+        assert np.array_equal(rec["hm_idx"], aux["hm_idx"]), f"frame {i}: heat-map argmax differs"
+        assert np.array_equal(rec["hm_score"], aux["hm_score"]), f"frame {i}: heat-map scores differ"
+        n = int(rec["n_det"])
+        assert n == len(aux["dets"]), f"frame {i}: {n} detections vs {len(aux['dets'])}"
+        got = np.stack([rec["det"][k][:n] for k in ("x1", "y1", "x2", "y2", "conf")], 1)
+        assert np.array_equal(got, aux["dets"][:, :5]), f"frame {i}: boxes/conf differ"
+        assert np.array_equal(rec["det"]["cls"][:n], aux["dets"][:, 5].astype(np.int32))
+        if aux["H"] is None:
+            assert not rec["H_valid"]
+        else:
+            assert rec["H_valid"] and np.array_equal(rec["H"].reshape(3, 3), aux["H"]), f"frame {i}: H differs"
+        assert _canon(records.to_reference_dict(rec, i)) == _canon(oref), f"frame {i}: record differs"
+    cm.handle.close()
+
+
+def test_f16_path_within_tolerance(state_dicts, frames, oracle_steps):
+    from eagle_amd.coordinate_model import CoordinateModel
+    from oracle import prims as P
+    hs, ys = state_dicts
+    cm = CoordinateModel(precision="f16", batch=3, hrnet_state_dict=hs, detector_state_dict=ys)
+    recs = cm.process_records(frames)
+    exact = total = 0
+    for i, (rec, (oref, aux)) in enumerate(zip(recs, oracle_steps)):
+        sig = P.sigmoid(aux["logits"][0])                  # fp32 oracle heat-maps [135,240,57]
+        flat = sig.reshape(-1, 57)
+        for c in range(57):
+            total += 1
+            gi = int(rec["hm_idx"][c])
+            if gi == int(aux["hm_idx"][c]):
+                exact += 1
+            # near-tie rule: the fp16 path's maximum must be (almost) as high as the fp32 maximum
+            assert flat[gi, c] >= aux["hm_score"][c] - 0.02, f"frame {i} ch {c}: fp16 argmax is not a near-maximum"
+            assert abs(float(rec["hm_score"][c]) - float(aux["hm_score"][c])) < 0.02
+        assert abs(int(rec["n_candidates"]) - int((aux["rows"][:, 4:].max(1) > 0.15).sum())) <= 0.1 * max(50, rec["n_candidates"])
+    assert exact >= 0.85 * total, f"only {exact}/{total} heat-map maxima identical between fp16 path and fp32 oracle"
+    cm.handle.close()
+
+
+def test_batch_invariance(state_dicts, frames):
+    """Results must not depend on the batch size or on a frame's position in the batch (fp16 path)."""
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    a = CoordinateModel(precision="f16", batch=1, hrnet_state_dict=hs, detector_state_dict=ys)
+    ra = a.process_records(frames)
+    a.handle.close()
+    b = CoordinateModel(precision="f16", batch=4, hrnet_state_dict=hs, detector_state_dict=ys, use_graph=True)
+    rb = b.process_records(frames[::-1])[::-1]
+    rb2 = b.process_records(frames[::-1])[::-1]          # graph replay
+    b.handle.close()
+    assert ra.tobytes() == rb.tobytes() == rb2.tobytes()

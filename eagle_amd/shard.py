@@ -1,0 +1,71 @@
+"""Frame sharding across the GPUs of one node: one process per GPU, rank r owns the contiguous chunk
+``[r*ceil(F/R), min(F, (r+1)*ceil(F/R)))``, weights replicated, no communication during the clip, and ONE collective
+at the end: an all-gather of the fixed-size per-frame records.
+
+Two transports for that one collective:
+  * ``rccl``  — the library's own ``eagle_gather`` (ncclAllGather on the handle's stream; RCCL over xGMI);
+  * ``dist``  — ``torch.distributed.all_gather`` on the default process group (gloo in the CPU tests, RCCL when the
+               group was created with backend "nccl").
+The reference has no multi-process path at all (single process, single device: coordinate_model.py:23-29)."""
+import numpy as np
+
+from .lib import RESULT_DTYPE
+
+
+def chunk_size(n_frames, world):
+    return -(-n_frames // world)
+
+
+def shard_range(n_frames, rank, world):
+    c = chunk_size(n_frames, world)
+    return min(n_frames, rank * c), min(n_frames, (rank + 1) * c)
+
+
+def _pad(local, c):
+    if len(local) == c:
+        return np.ascontiguousarray(local)
+    out = np.zeros(c, local.dtype)
+    out[: len(local)] = local
+    return out
+
+
+def gather_records(local, n_frames, rank, world, handle=None, transport="rccl"):
+    """local: this rank's records (structured array).  Returns all ``n_frames`` records in frame order on every rank."""
+    if world == 1:
+        return np.ascontiguousarray(local)
+    c = chunk_size(n_frames, world)
+    padded = _pad(local, c)
+    if transport == "rccl":
+        if handle is None:
+            raise ValueError("transport='rccl' needs the library handle (eagle_comm_init must have been called)")
+        allr = handle.gather(padded, world)
+    elif transport == "dist":
+        import torch
+        import torch.distributed as dist
+        raw = torch.from_numpy(padded.view(np.uint8).reshape(-1).copy())
+        if dist.get_backend() == "nccl":
+            raw = raw.cuda()
+        outs = [torch.empty_like(raw) for _ in range(world)]
+        dist.all_gather(outs, raw)
+        allr = np.concatenate([o.cpu().numpy() for o in outs]).view(local.dtype)
+    else:
+        raise ValueError(transport)
+    keep = []
+    for r in range(world):
+        lo, hi = shard_range(n_frames, r, world)
+        keep.append(allr[r * c: r * c + (hi - lo)])
+    return np.concatenate(keep)
+
+
+def init_rccl(handle, rank, world):
+    """Bootstrap the library's RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed broadcasts it."""
+    import torch
+    import torch.distributed as dist
+    from . import lib
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(lib.comm_unique_id()), dtype=torch.uint8).clone()
+    if dist.get_backend() == "nccl":
+        uid = uid.cuda()
+    dist.broadcast(uid, 0)
+    handle.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))

@@ -1,0 +1,182 @@
+"""Generates the committed golden fixtures by RUNNING THE REFERENCE in the build container (it cannot travel to
+the GPU box).  Usage:  PYTHONPATH=/root/repo python tests/golden/make_golden.py
+
+1. pitch_tables.json   — dumped from the reference's eagle/utils/pitch.py (pins SURVEY §8 row a14).
+2. hrnet_golden.npz    — the reference's own ``KeypointModel(57)`` (eagle/models/keypoint_hrnet.py, imported by file
+   path) loaded with this repo's seeded synthetic state-dict (strict=True), run on seeded inputs; stores
+   ``get_keypoints`` tuples and strided logits (pins rows a2, a3).
+3. loop_golden.json    — the reference's own ``CoordinateModel.get_coordinates`` loop body
+   (eagle/models/coordinate_model.py:277-415) and ``detect_objects`` / ``detect_keypoints`` executed with the four
+   missing third-party packages stubbed: the *control logic, integer rules and record layout are the reference's*,
+   while cv2.findHomography / perspectiveTransform / fitLine are served by this repo's restatements
+   (oracle/eo_prims.c) and the two networks by canned outputs.  Pins rows a4, a5 (minus fitLine), a9, a10 (point
+   selection + inlier filtering), a11, a12, a13 of the host-logic oracle.
+Only data (inputs + expected outputs) is written; no reference source text is stored."""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from eagle_amd import synth, weights  # noqa: E402
+from oracle import prims as P  # noqa: E402
+
+
+def load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+# ------------------------------------------------------------------------------------------------------------ 1
+def dump_pitch():
+    pitch = load_by_path("ref_pitch", f"{REF}/eagle/utils/pitch.py")
+    out = {"INTERSECTION_TO_PITCH_POINTS": {str(k): v for k, v in pitch.INTERSECTION_TO_PITCH_POINTS.items()},
+           "NOT_ON_PLANE": list(pitch.NOT_ON_PLANE),
+           "GROUND_TRUTH_POINTS": [[k, list(v)] for k, v in pitch.GROUND_TRUTH_POINTS.items()]}
+    json.dump(out, open(f"{HERE}/pitch_tables.json", "w"), indent=0)
+
+
+# ------------------------------------------------------------------------------------------------------------ 2
+def dump_hrnet():
+    kh = load_by_path("ref_kh", f"{REF}/eagle/models/keypoint_hrnet.py")
+    sd = weights.make_hrnet_state_dict(0)
+    model = kh.KeypointModel(57).eval()
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    out = {}
+    with torch.no_grad():
+        # small seeded input (odd sizes: exercises 25->13->7->4 style down/up-sampling)
+        x = np.random.default_rng(11).standard_normal((2, 100, 148, 3)).astype(np.float32)
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+        out["small_logits"] = model.forward_unnormalized(xt).permute(0, 2, 3, 1).numpy()
+        kps = model.get_keypoints(xt)
+        out["small_kp"] = np.array([[list(t) for t in f] + [[-1, 0, 0, 0]] * (57 - len(f)) for f in kps], np.float64)
+        # one full-resolution frame, preprocessed by this repo's preprocess restatement
+        from oracle import host
+        xf = host.preprocess_keypoints(synth.frame(0, 0))
+        xft = torch.from_numpy(xf).permute(0, 3, 1, 2).contiguous()
+        lg = model.forward_unnormalized(xft).permute(0, 2, 3, 1).numpy()
+        out["full_logits_strided"] = lg[:, ::8, ::8].copy()
+        kpf = model.get_keypoints(xft)[0]
+        out["full_kp"] = np.array([list(t) for t in kpf] + [[-1, 0, 0, 0]] * (57 - len(kpf)), np.float64)
+    np.savez_compressed(f"{HERE}/hrnet_golden.npz", **out)
+    print("hrnet golden:", {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------------------------ 3
+def install_stubs():
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_BGR2RGB, cv2.COLOR_BGR2GRAY, cv2.COLOR_BGR2HSV = 4, 6, 40
+    cv2.RANSAC, cv2.RHO, cv2.LMEDS, cv2.DIST_L2 = 8, 16, 4, 2
+    cv2.TERM_CRITERIA_EPS, cv2.TERM_CRITERIA_COUNT = 2, 1
+    cv2.cvtColor = lambda img, code: img[..., 0] if code == 6 else img
+
+    def find_h(src, dst, method, thr=None):
+        if method != 8:
+            return None, None
+        H, mask = P.find_homography_ransac(src, dst, 5.0 if thr is None else thr)
+        return (H, mask.reshape(-1, 1)) if H is not None else (None, None)
+
+    cv2.findHomography = find_h
+    cv2.perspectiveTransform = lambda pts, H: P.perspective_transform(np.asarray(pts, np.float32).reshape(-1, 2), H).reshape(np.asarray(pts).shape)
+    cv2.fitLine = lambda pts, *a: P.fit_line_l2(np.asarray(pts, np.float32).reshape(-1, 2)).reshape(4, 1)
+    sys.modules["cv2"] = cv2
+    ul = types.ModuleType("ultralytics"); ul.YOLO = object; sys.modules["ultralytics"] = ul
+    bm = types.ModuleType("boxmot"); bm.BotSort = object; sys.modules["boxmot"] = bm
+    A = types.ModuleType("albumentations")
+    A.Compose = A.Resize = A.Normalize = lambda *a, **k: None
+    Ap = types.ModuleType("albumentations.pytorch"); Ap.ToTensorV2 = lambda *a, **k: None
+    sys.modules["albumentations"] = A; sys.modules["albumentations.pytorch"] = Ap
+
+
+class _Boxes:
+    def __init__(self, d):
+        d = np.asarray(d, np.float32).reshape(-1, 6)
+        self.xyxy, self.conf, self.cls = torch.from_numpy(d[:, :4].copy()), torch.from_numpy(d[:, 4].copy()), torch.from_numpy(d[:, 5].copy())
+
+
+def make_cases():
+    """(keypoint tuples per frame, detections per frame).  Geometry comes from the synthetic camera so that the
+    homography is meaningful; some cases add collisions, off-plane labels, outliers, <4 plane points, no detections."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for ci in range(8):
+        vis = synth.visible_landmarks(ci, 13 * ci)
+        kp = []
+        for idx, (x, y) in sorted(vis.items()):
+            if rng.random() < 0.75:
+                xn = min(239, int(round(x / 1280 * 239))) / 239
+                yn = min(134, int(round(y / 720 * 134))) / 134
+                kp.append((idx, xn, yn, float(np.float32(rng.uniform(0.25, 0.99)))))
+        if ci == 1:   # two labels on one heat-map pixel with different scores, a third with equal score
+            kp.append((30, kp[0][1], kp[0][2], float(np.float32(0.995))))
+            kp.append((31, kp[1][1], kp[1][2], kp[1][3]))
+        if ci == 2:   # off-plane goal-post tops are labelled but never used for H
+            kp += [(0, 0.1, 0.2, 0.9), (1, 0.12, 0.2, 0.9), (24, 0.8, 0.2, 0.9)]
+        if ci == 3:   # gross outliers
+            kp = [(i, float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), s) if k % 4 == 0 else (i, x, y, s) for k, (i, x, y, s) in enumerate(kp)]
+        if ci == 4:   # fewer than 4 plane points -> no homography
+            kp = kp[:2] + [(0, 0.3, 0.3, 0.8), (25, 0.6, 0.3, 0.8)]
+        if ci == 5:   # low scores: some below keypoint_conf, some below 0.01
+            kp = [(i, x, y, s * (0.02 if k % 3 == 0 else 1.0)) for k, (i, x, y, s) in enumerate(kp)]
+        kp.sort(key=lambda t: t[0])
+        nd = [12, 40, 0, 25, 9, 300, 3, 60][ci]
+        d = np.zeros((nd, 6), np.float32)
+        d[:, 0] = rng.uniform(-5, 1250, nd); d[:, 1] = rng.uniform(-5, 690, nd)
+        d[:, 2] = d[:, 0] + rng.uniform(4, 90, nd); d[:, 3] = d[:, 1] + rng.uniform(8, 160, nd)
+        d[:, [0, 2]] = d[:, [0, 2]].clip(0, 1280); d[:, [1, 3]] = d[:, [1, 3]].clip(0, 720)
+        d[:, 4] = np.sort(rng.uniform(0.15, 0.97, nd))[::-1]
+        d[:, 5] = rng.choice([0, 0, 0, 0, 1, 2, 3, 4], nd)
+        if ci == 6:
+            d[:, 5] = [2, 2, 2]; d[1, 4] = 0.2          # ball enumerate index with a gap
+        cases.append((kp, d))
+    return cases
+
+
+def dump_loop():
+    install_stubs()
+    pkg = types.ModuleType("eagle"); pkg.__path__ = [f"{REF}/eagle"]; sys.modules["eagle"] = pkg
+    sub = types.ModuleType("eagle.models"); sub.__path__ = [f"{REF}/eagle/models"]; sys.modules["eagle.models"] = sub
+    ut = types.ModuleType("eagle.utils"); ut.__path__ = [f"{REF}/eagle/utils"]; sys.modules["eagle.utils"] = ut
+    sys.modules["eagle.utils.pitch"] = load_by_path("eagle.utils.pitch", f"{REF}/eagle/utils/pitch.py")
+    sys.modules["eagle.models.keypoint_hrnet"] = load_by_path("eagle.models.keypoint_hrnet", f"{REF}/eagle/models/keypoint_hrnet.py")
+    cm = load_by_path("eagle.models.coordinate_model", f"{REF}/eagle/models/coordinate_model.py")
+    out = []
+    for kp, dets in make_cases():
+        m = object.__new__(cm.CoordinateModel)
+        m.device = "cpu"
+        m.class_names = {0: "Player", 1: "Goalkeeper", 2: "Ball", 3: "Referee", 4: "Staff members"}
+        m.keypoint_conf, m.detector_conf = 0.3, 0.35
+        m.lk_params = {}
+        m.transforms = lambda image: {"image": torch.zeros(3, 4, 4)}
+        km = types.SimpleNamespace()
+        km.unnormalized_model = [None, types.SimpleNamespace(weight=types.SimpleNamespace(data=torch.zeros(1)))]
+        km.get_keypoints = lambda x, kp=kp: [list(kp) for _ in range(x.shape[0])]
+        m.keypoint_model = km
+        m.detector_model = lambda frame, verbose=False, conf=0.15, dets=dets: [types.SimpleNamespace(boxes=_Boxes(dets))]
+        m.tracker = types.SimpleNamespace(update=lambda d, f: np.zeros((0, 8)))
+        frames = [np.zeros((720, 1280, 3), np.uint8)]
+        res = m.get_coordinates(frames, fps=1, num_homography=1, num_keypoint_detection=1, verbose=False)
+        objs = m.detect_objects(frames[0])
+        kps_only = m.detect_keypoints(frames[0])
+        out.append({"kp": [list(t) for t in kp], "dets": dets.tolist(),
+                    "record": json.loads(json.dumps(res[0], default=float)),
+                    "detect_objects": json.loads(json.dumps(objs, default=lambda o: o.tolist() if isinstance(o, np.ndarray) else float(o))),
+                    "detect_keypoints": json.loads(json.dumps(kps_only, default=float))})
+    json.dump(out, open(f"{HERE}/loop_golden.json", "w"))
+    print("loop golden:", len(out), "cases;", [(len(c["record"]["Keypoints"]), c["record"]["Boundaries"][0] is not None) for c in out])
+
+
+if __name__ == "__main__":
+    dump_pitch()
+    dump_hrnet()
+    dump_loop()

@@ -1,0 +1,146 @@
+"""CPU tests: the oracle's host-logic restatement against the reference's OWN loop body
+(eagle/models/coordinate_model.py:277-415, :480-518, :557-628 executed with stubbed third-party packages by
+tests/golden/make_golden.py) and against independent float64 solvers for the cv2 restatements."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _canon(d):
+    if isinstance(d, dict):
+        return {str(k): _canon(v) for k, v in d.items() if not str(k).startswith("_")}
+    if isinstance(d, (list, tuple)):
+        return [_canon(v) for v in d]
+    if isinstance(d, (np.integer,)):
+        return int(d)
+    if isinstance(d, (np.floating,)):
+        return float(d)
+    return d
+
+
+CASES = json.load(open(os.path.join(HERE, "golden", "loop_golden.json")))
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_loop_body_matches_reference(ci):
+    from oracle import host
+    c = CASES[ci]
+    dets = np.array(c["dets"], np.float32).reshape(-1, 6)
+    decoded = [tuple(t) for t in c["kp"]]
+    decoded = [(int(i), x, y, s) for i, x, y, s in decoded if s > 0.01]            # kh.py:592
+    kps = host.keypoints_from_decoded(decoded, 720, 1280)
+    assert _canon(kps) == c["detect_keypoints"]
+    objects = host.objects_from_detections(dets, 720, 1280)
+    assert _canon(objects) == c["detect_objects"]
+    if len(kps) >= 2:
+        kps = host.synthesize_keypoints(kps)
+    H, kps = host.solve_homography(kps)
+    rec = {"Coordinates": host.project_objects(objects, H), "Time": "00:00", "Keypoints": kps,
+           "Boundaries": host.boundaries(H, 720, 1280)}
+    assert _canon(rec) == c["record"]
+
+
+def test_dlt_matches_numpy_svd():
+    from oracle import prims as P
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        Ht = np.array([[rng.uniform(.05, .2), rng.uniform(-.05, .05), rng.uniform(-30, 30)],
+                       [rng.uniform(-.05, .05), rng.uniform(.05, .2), rng.uniform(-30, 30)],
+                       [rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]])
+        src = rng.uniform(0, 1280, (12, 2))
+        p = np.c_[src, np.ones(12)] @ Ht.T
+        dst = p[:, :2] / p[:, 2:]
+        H = P.dlt_homography(src, dst)
+        assert np.abs(H - Ht).max() < 1e-8 * np.abs(Ht).max() + 1e-9
+        # independent: plain (un-normalised) DLT by SVD in float64
+        A = []
+        for (X, Y), (x, y) in zip(src, dst):
+            A.append([X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x]); A.append([0, 0, 0, X, Y, 1, -y * X, -y * Y, -y])
+        h = np.linalg.svd(np.array(A))[2][-1]; h = (h / h[8]).reshape(3, 3)
+        assert np.abs(H - h).max() < 1e-6
+
+
+def test_ransac_rejects_outliers_and_lm_polishes():
+    from oracle import prims as P
+    rng = np.random.default_rng(1)
+    Ht = np.array([[0.08, 0.01, 5.0], [0.0, 0.09, -3.0], [1e-5, 2e-5, 1.0]])
+    src = rng.uniform(0, 1280, (30, 2)).astype(np.float32)
+    p = np.c_[src, np.ones(30)] @ Ht.T
+    dst = (p[:, :2] / p[:, 2:]).astype(np.float32)
+    dst[:6] += rng.uniform(20, 40, (6, 2)).astype(np.float32)           # 6 gross outliers (> 5 m)
+    H, mask = P.find_homography_ransac(src, dst, 5.0)
+    assert mask[:6].sum() == 0 and mask[6:].all()
+    assert np.abs(H - Ht).max() < 1e-4
+    assert P.find_homography_ransac(src[:3], dst[:3])[0] is None
+
+
+def test_perspective_transform_closed_form():
+    from oracle import prims as P
+    H = np.array([[0.1, 0.02, 3.0], [0.01, 0.12, -2.0], [1e-4, -2e-4, 1.0]])
+    pts = np.array([[0, 0], [1280, 720], [640.5, 360.25]], np.float32)
+    out = P.perspective_transform(pts, H)
+    for (x, y), o in zip(pts.astype(np.float64), out):
+        w = H[2, 0] * x + H[2, 1] * y + H[2, 2]
+        assert np.allclose(o, [(H[0, 0] * x + H[0, 1] * y + H[0, 2]) / w, (H[1, 0] * x + H[1, 1] * y + H[1, 2]) / w], rtol=1e-6)
+
+
+def test_fit_line_is_principal_axis():
+    from oracle import prims as P
+    rng = np.random.default_rng(2)
+    t = rng.uniform(-50, 50, 9)
+    pts = np.stack([100 + 0.8 * t, 40 - 0.6 * t], 1) + rng.normal(0, 0.05, (9, 2))
+    vx, vy, x0, y0 = P.fit_line_l2(pts.astype(np.float32))
+    assert abs(abs(vx * 0.8 - vy * 0.6) - 1.0) < 1e-3
+    assert np.allclose([x0, y0], pts.mean(0), atol=1e-3)
+
+
+def test_nms_known_answers():
+    from oracle import host
+    def row(cx, cy, w, h, probs):
+        return [cx, cy, w, h] + probs
+    rows = np.array([
+        row(100, 100, 40, 80, [0.9, 0, 0, 0, 0]),
+        row(102, 101, 40, 80, [0.8, 0, 0, 0, 0]),      # IoU with #0 ~0.9 -> suppressed
+        row(102, 101, 40, 80, [0, 0.7, 0, 0, 0]),      # same box, other class -> kept (class offset)
+        row(300, 200, 20, 20, [0.1, 0.05, 0, 0, 0]),   # below the 0.15 floor
+        row(130, 100, 40, 80, [0.6, 0, 0, 0, 0]),      # IoU with #0 = 0.14 -> kept
+        row(500, 150, 10, 10, [0, 0, 0.16, 0, 0]),
+    ], np.float32)
+    d = host.nms_and_scale(rows, 720, 1280, 384, 640)
+    assert d[:, 4].tolist() == pytest.approx([0.9, 0.7, 0.6, 0.16])
+    assert d[:, 5].astype(int).tolist() == [0, 1, 0, 2]
+    assert d[0, :4].tolist() == pytest.approx([160, 96, 240, 256])     # (x-0)/0.5, (y-12)/0.5
+    many = np.array([row(10 + 60 * (i % 20), 10 + 30 * (i // 20), 8, 8, [0.2 + 0.001 * i, 0, 0, 0, 0]) for i in range(400)], np.float32)
+    d = host.nms_and_scale(many, 720, 1280, 384, 640)
+    assert len(d) == 300 and np.all(np.diff(d[:, 4]) <= 0)             # max_det cap, descending confidence
+    assert len(host.nms_and_scale(np.zeros((0, 9), np.float32), 720, 1280, 384, 640)) == 0
+
+
+def test_resize_and_letterbox_spec():
+    from oracle import host, prims as P
+    img = np.random.default_rng(0).integers(0, 256, (8, 12, 3), dtype=np.uint8)
+    assert np.array_equal(P.resize_linear_u8c3(img, 8, 12), img)
+    half = P.resize_linear_u8c3(img, 4, 6)
+    exp = (img.reshape(4, 2, 6, 2, 3).astype(np.int32).sum((1, 3)) + 2) >> 2
+    assert np.array_equal(half, exp.astype(np.uint8))
+    const = np.full((9, 12, 3), 77, np.uint8)
+    assert np.all(P.resize_linear_u8c3(const, 6, 9) == 77)              # 11-bit coefficients sum to 2048
+    g = host.letterbox_geometry(720, 1280, 640)
+    assert (g["out_h"], g["out_w"], g["top"], g["new_h"]) == (384, 640, 12, 360)
+    g = host.letterbox_geometry(720, 1280, 960)
+    assert (g["out_h"], g["out_w"], g["top"]) == (544, 960, 2)
+    g = host.letterbox_geometry(1080, 1920, 640)
+    assert (g["out_h"], g["out_w"], g["new_h"], g["new_w"]) == (384, 640, 360, 640)
+    x, _ = host.preprocess_detector(np.zeros((720, 1280, 3), np.uint8))
+    assert x.shape == (1, 384, 640, 3) and x[0, 0, 0, 0] == np.float32(114) / np.float32(255) and x[0, 12, 0, 0] == 0
+
+
+def test_boundaries_exceptions_become_none():
+    from oracle import host
+    assert host.boundaries(None, 720, 1280) == [None] * 4
+    H = np.eye(3)                                       # corners map to themselves: left edge vertical -> ZeroDivisionError
+    assert host.boundaries(H, 720, 1280) == [None] * 4

@@ -1,0 +1,82 @@
+"""CPU tests: data tables, synthetic weights, and the C-ABI surface (load + symbols + struct sizes; no compute)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_pitch_tables_match_reference_dump():
+    from eagle_amd import pitch
+    g = json.load(open(os.path.join(HERE, "golden", "pitch_tables.json")))
+    assert {int(k): v for k, v in g["INTERSECTION_TO_PITCH_POINTS"].items()} == pitch.INTERSECTION_TO_PITCH_POINTS
+    assert list(pitch.NOT_ON_PLANE) == g["NOT_ON_PLANE"]
+    assert [[k, list(v)] for k, v in pitch.GROUND_TRUTH_POINTS.items()] == g["GROUND_TRUTH_POINTS"]   # values AND insertion order
+    assert sum(pitch.on_plane_mask()) == 53
+
+
+def test_generated_device_table_is_current():
+    txt = open(os.path.join(ROOT, "eagle_amd", "csrc", "pitch_table.h")).read()
+    assert "#define PT_NY 19" in txt and "#define PT_NX 19" in txt
+    from eagle_amd import pitch
+    for _, _, x, y, _ in pitch.LANDMARKS:
+        assert f"{{{x!r}, {y!r}}}" in txt
+
+
+def test_synthetic_weights_counts_and_determinism():
+    from eagle_amd import weights as W
+    sd = W.make_hrnet_state_dict(0)
+    assert len(sd) == 1754 and W.n_params(sd) == 63_619_593
+    assert len(W.hrnet_convs()) == 293
+    for v, n in (("n", 3_157_200), ("s", 11_166_560), ("m", 25_902_640), ("l", 43_691_520), ("x", 68_229_648)):
+        assert W.param_count(W.yolo_convs(v, 80), 16) == n               # published YOLOv8 parameter counts
+    assert W.param_count(W.yolo_convs("n", 5), 16) == 3_011_823
+    a, b = W.make_yolo_state_dict("n", 0), W.make_yolo_state_dict("n", 0)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    c = W.make_yolo_state_dict("n", 1)
+    assert not np.array_equal(a["model.0.conv.weight"], c["model.0.conv.weight"])
+
+
+def test_abi_library_loads_and_exports_every_declared_symbol():
+    from eagle_amd import lib
+    L = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "eagle.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(eagle_\w+)\s*\(", hdr, re.M))
+    assert declared and declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    for s in declared:
+        assert hasattr(L, s), s
+    cfg_sz, res_sz, det_sz, kp_sz = lib.abi_sizes()
+    assert cfg_sz == ctypes.sizeof(lib.EagleConfig)
+    assert (res_sz, det_sz, kp_sz) == (lib.RESULT_DTYPE.itemsize, lib.DET_DTYPE.itemsize, lib.KP_DTYPE.itemsize)
+    cfg = lib.default_config()
+    assert (cfg.frame_h, cfg.frame_w, cfg.det_imgsz) == (720, 1280, 640)
+    assert (cfg.keypoint_conf, cfg.detector_conf, cfg.ransac_thresh) == (0.3, 0.35, 5.0)
+    assert abs(cfg.detector_floor - 0.15) < 1e-7 and abs(cfg.nms_iou - 0.7) < 1e-7
+    assert (cfg.ransac_max_iters, cfg.lm_iters) == (2000, 10)
+
+
+def test_product_path_fails_loudly_without_gpu_or_library():
+    import pytest
+    from eagle_amd import lib
+    try:
+        import torch
+        has_gpu = torch.cuda.device_count() > 0
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(lib.EagleError):
+        lib.Handle()
+
+
+def test_product_does_not_import_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "eagle_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "eo_prims" not in src or f.endswith((".hip", ".h")) and "oracle/eo_prims.c" in src, f

@@ -1,7 +1,7 @@
 """Developer timing helper (not the judged bench): times the resident-input path for a few batch sizes."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eagle_amd import lib, synth, weights
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16"

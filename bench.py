@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the per-frame path (detect + keypoints + homography) at 1280x720.
+
+One "step" = one pass of the hot path over one device batch of ``--batch`` synthetic frames that are already
+resident in HBM (C ABI: eagle_process_device_frames).  Default run = BASELINE.json configs[1]: a 1000-frame
+1280x720 synthetic clip, YOLOv8-n detector + HRNet-W48 keypoint model, one MI355X (50 steps x 20 frames).
+Multi-GPU (driver launches one rank per GPU through torch.distributed.run): frames shard by contiguous chunk,
+weights replicated, no data-path collective; ONE all-gather of the fixed-size records at the end (inside the timed
+region); value = total frames of all ranks / max-over-ranks time  ("scaling": "weak").
+
+Prints ONE JSON line on rank 0.  The CPU oracle appears here only as the timed ``cpu_baseline`` leg."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_FRAME = 339.0e9          # SURVEY §8d / BASELINE.md §3: 4.85 G (yolov8n@384x640) + 334.15 G (HRNet-W48@540x960)
+MFMA_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def cpu_baseline(hs, ys, frames, n_frames, threads):
+    """The oracle's torch-CPU fp32 restatement of S(frame), timed on this host on a bounded sample."""
+    import torch
+    torch.set_num_threads(threads)
+    from oracle import pipeline
+    m = pipeline.OracleModel(hs, ys, backend="torch")
+    m.step(frames[0])                                  # warm-up (weight folding, MKLDNN primitives)
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        m.step(frames[i % len(frames)], i)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n_frames} frames of the same synthetic clip through oracle/pipeline.py (torch-CPU fp32 nets + "
+                      f"numpy/C host logic), {threads} threads of {os.cpu_count()} logical CPUs, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=20, help="frames per device step")
+    ap.add_argument("--detector", default="n")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--distinct", type=int, default=20, help="distinct synthetic frames generated (tiled to the clip)")
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from eagle_amd import lib, shard, synth, weights
+    B, K, W = a.batch, a.steps, a.warmup
+    hs = weights.make_hrnet_state_dict(0)
+    ys = weights.make_yolo_state_dict(a.detector, 0)
+    h = lib.Handle(device=local_rank, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
+                   batch=B, precision=lib.PREC_F16 if a.precision == "f16" else lib.PREC_F32,
+                   use_graph=0 if a.no_graph else 1)
+    weights.load_into(h, [hs, ys])
+    gather_used = a.gather
+    if world > 1 and a.gather == "rccl":
+        try:
+            shard.init_rccl(h, rank, world)
+        except Exception as e:                        # labelled, never silent: reported in the JSON line
+            print(f"[bench] rank {rank}: library RCCL bootstrap failed ({e}); using torch.distributed all_gather", file=sys.stderr)
+            gather_used = "dist"
+        flag = torch.tensor([1 if gather_used == "dist" else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            gather_used = "dist"
+
+    # this rank's contiguous chunk of the (weak-scaled) clip: (W+K)*B frames per rank, distinct per rank
+    n_local = K * B
+    base = synth.clip(seed=rank, n=min(a.distinct, B), h=a.height, w=a.width)
+    frames = np.concatenate([base] * (-(-B // len(base))))[:B]
+    d_frames = h.upload(frames)                       # inputs resident in HBM before the timed region
+    out = np.zeros(n_local, lib.RESULT_DTYPE)
+
+    def sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(W):
+        h.process_device(d_frames, B, out[:B])
+    sync()
+    t0 = time.perf_counter()
+    for k in range(K):
+        h.process_device(d_frames, B, out[k * B:(k + 1) * B])
+    if world > 1:
+        allrec = shard.gather_records(out, n_local * world, rank, world, handle=h, transport=gather_used)
+    else:
+        allrec = out
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_frames = n_local * world
+    assert len(allrec) == total_frames
+
+    # dominant kernel = the implicit-GEMM convolution family: per-launch HIP events on the launch stream
+    h.set_profiling(1)
+    prof_steps = 2
+    conv_ms = conv_flop = 0.0
+    n_conv = 0
+    for _ in range(prof_steps):
+        h.process_device(d_frames, B, out[:B])
+        t = h.timings()
+        conv_ms += t.conv_ms; conv_flop += t.conv_flop; n_conv += t.n_conv_launches
+    h.set_profiling(0)
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+
+    res = None
+    if rank == 0:
+        res = {
+            "metric": "frames/sec end-to-end (detect+keypoint+homography) @1280x720",
+            "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if a.precision == "f16" else "f32", "data": f"synthetic ({len(base)} distinct frames per rank tiled; seeded synthetic weights)",
+            "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
+                       "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}",
+                       "gather": "none" if world == 1 else gather_used, "hip_graph": not a.no_graph},
+            "roofline": {"bound": "mfma", "kernel": "conv_f16_kernel<KS,S,KC,NT> (all convolution launches)" if a.precision == "f16" else "conv_f32_kernel",
+                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3, "unit": "TFLOP/s",
+                         "frac": round(achieved / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
+                         "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
+                         "conv_ms_per_step": round(conv_ms / prof_steps, 3), "traffic": None},
+        }
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, os.cpu_count() or 1))
+    h.free(d_frames)
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -16,45 +16,78 @@
 namespace eagle {
 
 #define POST_T 256
+#define RANSAC_WIN (POST_T * 6)
+#define RNG_N 65536        // precomputed draws of cv::RNG(-1): the stream does not depend on the data
 #define DEPS 2.220446049250313e-16
 
-// ---- 9x9 symmetric eigen-solve (cyclic Jacobi), eigenvector of the smallest eigenvalue ----------------------
-__device__ void jacobi9_smallest(double A[9][9], double v[9])
+// ---- 9x9 symmetric eigen-solve: classic cyclic Jacobi on the upper triangle, eigenvector of the smallest
+// eigenvalue.  Same operations in the same order as oracle/eo_prims.c::eo_jacobi9_smallest.  Every index below is a
+// compile-time constant after unrolling, so a[][], V[][], d, b, z live in registers (no scratch).
+#define JROT(x, y) do { const double g_ = (x), h_ = (y); (x) = g_ - s * (h_ + g_ * tau); (y) = h_ + s * (g_ - h_ * tau); } while (0)
+__device__ __forceinline__ void jacobi9_smallest(double (&a)[9][9], double (&v)[9])
 {
-    double V[9][9];
-    for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < 8; ++p) for (int q = p + 1; q < 9; ++q) off += A[p][q] * A[p][q];
-        if (off < 1e-300) break;
+    double V[9][9], d[9], b[9], z[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+        d[i] = b[i] = a[i][i]; z[i] = 0.0;
+    }
+    for (int sweep = 1; sweep <= 50; ++sweep) {
+        double sm = 0.0;
+#pragma unroll
         for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 9; ++q) sm += fabs(a[p][q]);
+        if (sm == 0.0) break;
+        const double tresh = sweep < 4 ? 0.2 * sm / 81.0 : 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
             for (int q = p + 1; q < 9; ++q) {
-                const double apq = A[p][q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 9; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 9; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 9; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                const double g = 100.0 * fabs(a[p][q]);
+                if (sweep > 4 && fabs(d[p]) + g == fabs(d[p]) && fabs(d[q]) + g == fabs(d[q])) {
+                    a[p][q] = 0.0;
+                } else if (fabs(a[p][q]) > tresh) {
+                    double h = d[q] - d[p], t;
+                    if (fabs(h) + g == fabs(h)) {
+                        t = a[p][q] / h;
+                    } else {
+                        const double theta = 0.5 * h / a[p][q];
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c);
+                    h = t * a[p][q];
+                    z[p] -= h; z[q] += h; d[p] -= h; d[q] += h; a[p][q] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < p; ++j) JROT(a[j][p], a[j][q]);
+#pragma unroll
+                    for (int j = p + 1; j < q; ++j) JROT(a[p][j], a[j][q]);
+#pragma unroll
+                    for (int j = q + 1; j < 9; ++j) JROT(a[p][j], a[q][j]);
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) JROT(V[j][p], V[j][q]);
                 }
             }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { b[i] += z[i]; d[i] = b[i]; z[i] = 0.0; }
     }
     int m = 0;
-    for (int i = 1; i < 9; ++i) if (A[i][i] < A[m][m]) m = i;
-    for (int k = 0; k < 9; ++k) v[k] = V[k][m];
+    double dm = d[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) if (d[i] < dm) { dm = d[i]; m = i; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double r = V[k][0];
+#pragma unroll
+        for (int i = 1; i < 9; ++i) r = (m == i) ? V[k][i] : r;
+        v[k] = r;
+    }
 }
 
 // ---- normalised DLT ("runKernel") ---------------------------------------------------------------------------
-__device__ int dlt_homography(const double* src, const double* dst, const int* sel, int n, double* H)
+__device__ __noinline__ int dlt_homography(const double* src, const double* dst, const int* sel, int n, double* H)
 {
     double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
@@ -70,16 +103,21 @@ __device__ int dlt_homography(const double* src, const double* dst, const int* s
     if (fabs(sM[0]) < DEPS || fabs(sM[1]) < DEPS || fabs(sm[0]) < DEPS || fabs(sm[1]) < DEPS) return 0;
     sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
     double LtL[9][9];
-    for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) LtL[a][b] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int b = 0; b < 9; ++b) LtL[a][b] = 0.0;
     for (int i = 0; i < n; ++i) {
         const int k = sel ? sel[i] : i;
         const double X = (src[2 * k] - cM[0]) * sM[0], Y = (src[2 * k + 1] - cM[1]) * sM[1];
         const double x = (dst[2 * k] - cm[0]) * sm[0], y = (dst[2 * k + 1] - cm[1]) * sm[1];
         const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
         const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-        for (int a = 0; a < 9; ++a) for (int b = a; b < 9; ++b) LtL[a][b] += Lx[a] * Lx[b] + Ly[a] * Ly[b];
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+            for (int b = a; b < 9; ++b) LtL[a][b] += Lx[a] * Lx[b] + Ly[a] * Ly[b];
     }
-    for (int a = 0; a < 9; ++a) for (int b = 0; b < a; ++b) LtL[a][b] = LtL[b][a];
     double h[9];
     jacobi9_smallest(LtL, h);
     const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
@@ -101,6 +139,85 @@ __device__ __forceinline__ float reproj_err1(const double* src, const double* ds
     const double dx = (H[0] * X + H[1] * Y + H[2]) * ww - dst[2 * i];
     const double dy = (H[3] * X + H[4] * Y + H[5]) * ww - dst[2 * i + 1];
     return (float)(dx * dx + dy * dy);
+}
+
+// ---- minimal-sample model: normalised 8x8 system (h33 = 1), Gaussian elimination with partial pivoting.
+// Operation-for-operation oracle/eo_prims.c::eo_h4_homography; all indices static -> the 8x9 system stays in registers
+// (row swaps are selects).
+__device__ __forceinline__ int h4_homography(const double* src, const double* dst, const int (&idx)[4], double (&H)[9])
+{
+    const int n = 4;
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    double px[4], py[4], qx[4], qy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int k = idx[i]; px[i] = src[2 * k]; py[i] = src[2 * k + 1]; qx[i] = dst[2 * k]; qy[i] = dst[2 * k + 1]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cM[0] += px[i]; cM[1] += py[i]; cm[0] += qx[i]; cm[1] += qy[i]; }
+    cM[0] /= n; cM[1] /= n; cm[0] /= n; cm[1] /= n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sM[0] += fabs(px[i] - cM[0]); sM[1] += fabs(py[i] - cM[1]);
+        sm[0] += fabs(qx[i] - cm[0]); sm[1] += fabs(qy[i] - cm[1]);
+    }
+    if (fabs(sM[0]) < DEPS || fabs(sM[1]) < DEPS || fabs(sm[0]) < DEPS || fabs(sm[1]) < DEPS) return 0;
+    sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
+    double M[8][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double X = (px[i] - cM[0]) * sM[0], Y = (py[i] - cM[1]) * sM[1];
+        const double x = (qx[i] - cm[0]) * sm[0], y = (qy[i] - cm[1]) * sm[1];
+        M[2 * i][0] = X; M[2 * i][1] = Y; M[2 * i][2] = 1; M[2 * i][3] = 0; M[2 * i][4] = 0; M[2 * i][5] = 0;
+        M[2 * i][6] = -x * X; M[2 * i][7] = -x * Y; M[2 * i][8] = x;
+        M[2 * i + 1][0] = 0; M[2 * i + 1][1] = 0; M[2 * i + 1][2] = 0; M[2 * i + 1][3] = X; M[2 * i + 1][4] = Y; M[2 * i + 1][5] = 1;
+        M[2 * i + 1][6] = -y * X; M[2 * i + 1][7] = -y * Y; M[2 * i + 1][8] = y;
+    }
+    bool fail_ = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int p = c; double best = fabs(M[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) { const double v = fabs(M[r][c]); if (v > best) { best = v; p = r; } }
+        fail_ = fail_ || (best < 1e-13);
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) {
+            const bool sw = (p == r);
+#pragma unroll
+            for (int j = c; j < 9; ++j) { const double t = M[c][j], u = M[r][j]; M[c][j] = sw ? u : t; M[r][j] = sw ? t : u; }
+        }
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = M[r][c] / M[c][c];
+#pragma unroll
+            for (int j = c + 1; j < 9; ++j) M[r][j] = M[r][j] - f * M[c][j];
+        }
+    }
+    if (fail_) return 0;
+    double h[9];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        double s = M[i][8];
+#pragma unroll
+        for (int j = i + 1; j < 8; ++j) s = s - M[i][j] * h[j];
+        h[i] = s / M[i][i];
+    }
+    h[8] = 1.0;
+    const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double t[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += iT[3 * r + k] * h[3 * k + c]; t[3 * r + c] = s; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += t[3 * r + k] * T[3 * k + c]; H[3 * r + c] = s; }
+    if (fabs(H[8]) < DEPS) return 0;
+    const double inv = 1.0 / H[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) H[k] *= inv;
+    H[8] = 1.0;
+    return 1;
 }
 
 __device__ int collinear_last(const double* p, const int* idx, int count)
@@ -148,22 +265,20 @@ __device__ int ransac_update_iters(double p, double ep, int model_points, int ma
     return (ld >= 0 || -ln >= max_iters * (-ld)) ? max_iters : (int)lrint(ln / ld);
 }
 
-// ---- Levenberg-Marquardt polish ------------------------------------------------------------------------------
-__device__ void lm_residual(const double* src, const double* dst, int n, const double* h, double* r, double* J)
+// ---- Levenberg-Marquardt polish: workgroup-cooperative, same summation order as oracle/eo_prims.c::eo_lm_refine ------
+__device__ __forceinline__ void lm_point(const double* src, const double* dst, int i, const double* h, double* r, double* J)
 {
-    for (int i = 0; i < n; ++i) {
-        const double Mx = src[2 * i], My = src[2 * i + 1];
-        double ww = h[6] * Mx + h[7] * My + 1.0;
-        ww = fabs(ww) > DEPS ? 1.0 / ww : 0.0;
-        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
-        r[2 * i] = xi - dst[2 * i]; r[2 * i + 1] = yi - dst[2 * i + 1];
-        if (J) {
-            double* a = J + (size_t)(2 * i) * 8; double* b = a + 8;
-            a[0] = Mx * ww; a[1] = My * ww; a[2] = ww; a[3] = a[4] = a[5] = 0.0;
-            a[6] = -Mx * ww * xi; a[7] = -My * ww * xi;
-            b[0] = b[1] = b[2] = 0.0; b[3] = Mx * ww; b[4] = My * ww; b[5] = ww;
-            b[6] = -Mx * ww * yi; b[7] = -My * ww * yi;
-        }
+    const double Mx = src[2 * i], My = src[2 * i + 1];
+    double ww = h[6] * Mx + h[7] * My + 1.0;
+    ww = fabs(ww) > DEPS ? 1.0 / ww : 0.0;
+    const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+    r[2 * i] = xi - dst[2 * i]; r[2 * i + 1] = yi - dst[2 * i + 1];
+    if (J) {
+        double* a = J + (size_t)(2 * i) * 8; double* b = a + 8;
+        a[0] = Mx * ww; a[1] = My * ww; a[2] = ww; a[3] = a[4] = a[5] = 0.0;
+        a[6] = -Mx * ww * xi; a[7] = -My * ww * xi;
+        b[0] = b[1] = b[2] = 0.0; b[3] = Mx * ww; b[4] = My * ww; b[5] = ww;
+        b[6] = -Mx * ww * yi; b[7] = -My * ww * yi;
     }
 }
 __device__ int solve8(double A[8][8], double b[8], double x[8])
@@ -190,46 +305,6 @@ __device__ int solve8(double A[8][8], double b[8], double x[8])
 __device__ const double D_P10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5,
                                      1e-4, 1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10,
                                      1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
-// r, rn: 2n doubles; J: 16n doubles (caller-provided scratch)
-__device__ void lm_refine(const double* src, const double* dst, int n, double* H, int max_iters, double* r, double* rn, double* J)
-{
-    double h[8];
-    for (int k = 0; k < 8; ++k) h[k] = H[k];
-    lm_residual(src, dst, n, h, r, J);
-    double S = 0;
-    for (int i = 0; i < 2 * n; ++i) S += r[i] * r[i];
-    int lambdaLg10 = -3;
-    for (int it = 0; it < max_iters; ++it) {
-        double A[8][8], g[8];
-        for (int a = 0; a < 8; ++a) {
-            g[a] = 0;
-            for (int i = 0; i < 2 * n; ++i) g[a] += J[(size_t)i * 8 + a] * r[i];
-            for (int b = 0; b < 8; ++b) { double s = 0; for (int i = 0; i < 2 * n; ++i) s += J[(size_t)i * 8 + a] * J[(size_t)i * 8 + b]; A[a][b] = s; }
-        }
-        int improved = 0;
-        for (int tries = 0; tries < 16 && !improved; ++tries) {
-            double Ap[8][8], d[8], hn[8], gm[8];
-            const double lam = D_P10[lambdaLg10 + 16];
-            for (int a = 0; a < 8; ++a) { for (int b = 0; b < 8; ++b) Ap[a][b] = A[a][b]; Ap[a][a] += lam * A[a][a]; gm[a] = -g[a]; }
-            if (!solve8(Ap, gm, d)) { lambdaLg10 = lambdaLg10 + 1 > 16 ? 16 : lambdaLg10 + 1; continue; }
-            for (int k = 0; k < 8; ++k) hn[k] = h[k] + d[k];
-            lm_residual(src, dst, n, hn, rn, nullptr);
-            double Sn = 0;
-            for (int i = 0; i < 2 * n; ++i) Sn += rn[i] * rn[i];
-            if (Sn < S) {
-                for (int k = 0; k < 8; ++k) h[k] = hn[k];
-                S = Sn; improved = 1;
-                lambdaLg10 = lambdaLg10 - 1 < -16 ? -16 : lambdaLg10 - 1;
-            } else {
-                lambdaLg10 = lambdaLg10 + 1 > 16 ? 16 : lambdaLg10 + 1;
-            }
-        }
-        if (!improved) break;
-        lm_residual(src, dst, n, h, r, J);
-    }
-    for (int k = 0; k < 8; ++k) H[k] = h[k];
-    H[8] = 1.0;
-}
 
 // ---- workgroup-level findHomography(RANSAC) -------------------------------------------------------------------
 struct HomoShared {
@@ -238,21 +313,91 @@ struct HomoShared {
     double cand[POST_T][9];
     double best[9];
     double lm_r[2 * EAGLE_MAX_KP], lm_rn[2 * EAGLE_MAX_KP], lm_J[16 * EAGLE_MAX_KP];
+    double lm_A[8][8], lm_g[8], lm_h[8], lm_hn[8];
+    double lm_S;
+    int lm_lambda, lm_flag;            // flag: 0 = solve failed (retry), 1 = candidate ready, 2 = improved, 3 = stop
     int subset[POST_T][4];
     int good[POST_T];
-    signed char state[POST_T];     // 0: no subset found, 1: DLT failed, 2: model ok
+    alignas(16) unsigned char code[POST_T];   // per attempt: 255 degenerate subset (rejected), 254 model failed, else inlier count
     unsigned char mask[EAGLE_MAX_KP];
-    int niters, max_good, ok, stop;
-    unsigned long long rng;
+    int niters, max_good, ok, stop, iter, fail_run, ni;
+    int pos, natt, newpos;             // cursor into the precomputed MWC stream; attempts parsed this round
+    unsigned tuple[RANSAC_WIN];        // 4 packed point indices of the sampling attempt starting at window position w
+    unsigned char len[RANSAC_WIN];     // draws it consumes (0 = stream exhausted)
+    int start[POST_T];
 };
 
+// refine S.best over the ni inlier points in S.s2/S.d2 (all threads call; barriers inside)
+__device__ void lm_refine_block(HomoShared& S, int n, int max_iters)
+{
+    const int tid = threadIdx.x;
+    if (tid < 8) S.lm_h[tid] = S.best[tid];
+    __syncthreads();
+    for (int i = tid; i < n; i += POST_T) lm_point(S.s2, S.d2, i, S.lm_h, S.lm_r, S.lm_J);
+    __syncthreads();
+    if (tid == 0) {
+        double Ssum = 0;
+        for (int i = 0; i < 2 * n; ++i) Ssum += S.lm_r[i] * S.lm_r[i];
+        S.lm_S = Ssum; S.lm_lambda = -3;
+    }
+    __syncthreads();
+    for (int it = 0; it < max_iters; ++it) {
+        if (tid < 64) {
+            const int a = tid >> 3, b = tid & 7;
+            double acc = 0;
+            for (int i = 0; i < 2 * n; ++i) acc += S.lm_J[(size_t)i * 8 + a] * S.lm_J[(size_t)i * 8 + b];
+            S.lm_A[a][b] = acc;
+        } else if (tid < 72) {
+            const int a = tid - 64;
+            double acc = 0;
+            for (int i = 0; i < 2 * n; ++i) acc += S.lm_J[(size_t)i * 8 + a] * S.lm_r[i];
+            S.lm_g[a] = acc;
+        }
+        __syncthreads();
+        int improved = 0;
+        for (int tries = 0; tries < 16 && !improved; ++tries) {
+            if (tid == 0) {
+                double Ap[8][8], d[8], gm[8];
+                const double lam = D_P10[S.lm_lambda + 16];
+                for (int a = 0; a < 8; ++a) { for (int b = 0; b < 8; ++b) Ap[a][b] = S.lm_A[a][b]; Ap[a][a] += lam * S.lm_A[a][a]; gm[a] = -S.lm_g[a]; }
+                if (!solve8(Ap, gm, d)) { S.lm_lambda = S.lm_lambda + 1 > 16 ? 16 : S.lm_lambda + 1; S.lm_flag = 0; }
+                else { for (int k = 0; k < 8; ++k) S.lm_hn[k] = S.lm_h[k] + d[k]; S.lm_flag = 1; }
+            }
+            __syncthreads();
+            if (S.lm_flag == 0) { __syncthreads(); continue; }          // uniform
+            for (int i = tid; i < n; i += POST_T) lm_point(S.s2, S.d2, i, S.lm_hn, S.lm_rn, nullptr);
+            __syncthreads();
+            if (tid == 0) {
+                double Sn = 0;
+                for (int i = 0; i < 2 * n; ++i) Sn += S.lm_rn[i] * S.lm_rn[i];
+                if (Sn < S.lm_S) {
+                    for (int k = 0; k < 8; ++k) S.lm_h[k] = S.lm_hn[k];
+                    S.lm_S = Sn; S.lm_flag = 2;
+                    S.lm_lambda = S.lm_lambda - 1 < -16 ? -16 : S.lm_lambda - 1;
+                } else {
+                    S.lm_lambda = S.lm_lambda + 1 > 16 ? 16 : S.lm_lambda + 1;
+                }
+            }
+            __syncthreads();
+            improved = S.lm_flag == 2;
+            __syncthreads();
+        }
+        if (!improved) break;
+        for (int i = tid; i < n; i += POST_T) lm_point(S.s2, S.d2, i, S.lm_h, S.lm_r, S.lm_J);
+        __syncthreads();
+    }
+    if (tid < 8) S.best[tid] = S.lm_h[tid];
+    if (tid == 8) S.best[8] = 1.0;
+    __syncthreads();
+}
+
 // img/world: float [n][2].  On return (after a barrier) S.ok, S.best, S.mask are valid for every thread.
-__device__ void find_homography_block(HomoShared& S, const float* img, const float* world, int n, double thresh,
-                                      int max_iters, int lm_iters)
+__device__ void find_homography_block(HomoShared& S, const unsigned* __restrict__ rng_raw, const float* img, const float* world,
+                                      int n, double thresh, int max_iters, int lm_iters)
 {
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * n; i += POST_T) { S.src[i] = (double)img[i]; S.dst[i] = (double)world[i]; }
-    if (tid == 0) { S.ok = 0; S.niters = max_iters; S.max_good = 0; S.stop = 0; S.rng = 0xffffffffffffffffULL; }
+    if (tid == 0) { S.ok = 0; S.niters = max_iters; S.max_good = 0; S.stop = 0; S.iter = 0; S.fail_run = 0; S.pos = 0; }
     __syncthreads();
     if (n < 4) return;
     if (n == 4) {
@@ -266,60 +411,82 @@ __device__ void find_homography_block(HomoShared& S, const float* img, const flo
         return;
     }
     const float t2 = (float)(thresh * thresh);
-    for (int base = 0; ; base += POST_T) {
-        if (base >= S.niters || S.stop) break;        // uniform (shared values, read after a barrier)
-        if (tid == 0) {                              // draw the subsets of iterations [base, base+POST_T) serially
-            unsigned long long rng = S.rng;
-            int k = 0;
-            for (; k < POST_T && base + k < S.niters; ++k) {
-                int idx[4], found = 0;
-                for (int attempt = 0; attempt < 1000 && !found; ++attempt) {
-                    for (int i = 0; i < 4; ++i) {
-                        int v, dup;
-                        do {
-                            v = (int)(rng_next(&rng) % (unsigned)n);
-                            dup = 0;
-                            for (int j = 0; j < i; ++j) dup |= (idx[j] == v);
-                        } while (dup);
-                        idx[i] = v;
+    for (;;) {
+        if (S.stop || S.iter >= S.niters) break;       // uniform: shared values, read after a barrier
+        // (a) every window position: the sampling attempt that would start at that draw (getSubset's inner loops:
+        //     draw until 4 distinct indices), its packed indices and the number of draws it consumes
+        for (int w = tid; w < RANSAC_WIN; w += POST_T) {
+            int j = S.pos + w, cnt = 0, idx[4] = {0, 0, 0, 0};
+            const int j0 = j;
+            while (cnt < 4 && j < RNG_N && j - j0 < 250) {
+                const int v = (int)(rng_raw[j++] % (unsigned)n);
+                bool dup = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dup = dup || (q < cnt && idx[q] == v);
+                if (!dup) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q == cnt) idx[q] = v;
+                    ++cnt;
+                }
+            }
+            S.len[w] = cnt == 4 ? (unsigned char)(j - j0) : 0;
+            S.tuple[w] = (unsigned)idx[0] | ((unsigned)idx[1] << 8) | ((unsigned)idx[2] << 16) | ((unsigned)idx[3] << 24);
+        }
+        __syncthreads();
+        if (tid == 0) {                               // (b) hop chain: attempt k starts where attempt k-1 stopped drawing
+            int p = 0, k = 0;
+            while (k < POST_T && p < RANSAC_WIN && S.len[p] > 0) { S.start[k++] = p; p += S.len[p]; }
+            S.natt = k; S.newpos = S.pos + p;
+        }
+        __syncthreads();
+        if (tid < S.natt) {                           // (c) degeneracy test, 4-point model and its support, in parallel
+            const unsigned tp = S.tuple[S.start[tid]];
+            const int idx[4] = {(int)(tp & 255), (int)((tp >> 8) & 255), (int)((tp >> 16) & 255), (int)(tp >> 24)};
+            unsigned char code = 255;
+            if (check_subset4(S.src, S.dst, idx)) {
+                code = 254;
+                double Hc[9];
+                if (h4_homography(S.src, S.dst, idx, Hc)) {
+                    int good = 0;
+                    for (int i = 0; i < n; ++i) good += (reproj_err1(S.src, S.dst, i, Hc) <= t2);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) S.cand[tid][k] = Hc[k];
+                    code = (unsigned char)good;
+                }
+            }
+            S.code[tid] = code;
+        } else {
+            S.code[tid] = 255;
+        }
+        __syncthreads();
+        if (tid == 0) {                               // (d) replay the attempts in order = the sequential RANSAC loop
+            int iter = S.iter, fail_run = S.fail_run, niters = S.niters, max_good = S.max_good, stop = 0;
+            const int natt = S.natt;
+            if (natt == 0) stop = 1;                  // precomputed stream exhausted
+            for (int c16 = 0; c16 * 16 < natt && !stop && iter < niters; ++c16) {
+                const uint4 pk = *(const uint4*)&S.code[c16 * 16];
+                const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int k = c16 * 16 + b;
+                    const int code = (int)((wds[b >> 2] >> (8 * (b & 3))) & 255u);
+                    if (k < natt && !stop && iter < niters) {
+                        if (code == 255) {            // getSubset keeps drawing (at most 1000 attempts per iteration)
+                            if (++fail_run >= 1000) { if (iter == 0) max_good = -1; stop = 1; }
+                        } else {
+                            fail_run = 0;
+                            if (code != 254 && code > (max_good > 3 ? max_good : 3)) {
+                                for (int j = 0; j < 9; ++j) S.best[j] = S.cand[k][j];
+                                max_good = code;
+                                niters = ransac_update_iters(0.995, (double)(n - code) / n, 4, niters);
+                            }
+                            ++iter;
+                        }
                     }
-                    found = check_subset4(S.src, S.dst, idx);
-                }
-                S.state[k] = found ? 1 : 0;
-                for (int i = 0; i < 4; ++i) S.subset[k][i] = idx[i];
-                if (!found) { ++k; break; }
-            }
-            for (; k < POST_T; ++k) S.state[k] = -1;   // beyond the iteration bound / after a failed draw
-            S.rng = rng;
-        }
-        __syncthreads();
-        if (S.state[tid] == 1) {
-            double Hc[9];
-            int idx[4] = {S.subset[tid][0], S.subset[tid][1], S.subset[tid][2], S.subset[tid][3]};
-            if (dlt_homography(S.src, S.dst, idx, 4, Hc)) {
-                int good = 0;
-                for (int i = 0; i < n; ++i) good += (reproj_err1(S.src, S.dst, i, Hc) <= t2);
-                S.good[tid] = good;
-                for (int k = 0; k < 9; ++k) S.cand[tid][k] = Hc[k];
-                S.state[tid] = 2;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {                              // replay in iteration order
-            for (int k = 0; k < POST_T; ++k) {
-                const int iter = base + k;
-                if (iter >= S.niters) break;
-                const int st = S.state[k];
-                if (st < 0) break;
-                if (st == 0) { if (iter == 0) S.max_good = -1; S.stop = 1; break; }
-                if (st == 1) continue;
-                const int good = S.good[k];
-                if (good > (S.max_good > 3 ? S.max_good : 3)) {
-                    for (int j = 0; j < 9; ++j) S.best[j] = S.cand[k][j];
-                    S.max_good = good;
-                    S.niters = ransac_update_iters(0.995, (double)(n - good) / n, 4, S.niters);
                 }
             }
+            S.niters = niters; S.max_good = max_good; if (stop) S.stop = 1;
+            S.iter = iter; S.fail_run = fail_run; S.pos = S.newpos;
         }
         __syncthreads();
     }
@@ -332,15 +499,15 @@ __device__ void find_homography_block(HomoShared& S, const float* img, const flo
         for (int i = 0; i < n; ++i)
             if (S.mask[i]) { S.s2[2 * ni] = S.src[2 * i]; S.s2[2 * ni + 1] = S.src[2 * i + 1]; S.d2[2 * ni] = S.dst[2 * i]; S.d2[2 * ni + 1] = S.dst[2 * i + 1]; ++ni; }
         double Hr[9];
+        S.ni = 0;
         if (dlt_homography(S.s2, S.d2, nullptr, ni, Hr)) {
             for (int k = 0; k < 9; ++k) S.best[k] = Hr[k];
-            if (lm_iters > 0) {
-                lm_refine(S.s2, S.d2, ni, Hr, lm_iters, S.lm_r, S.lm_rn, S.lm_J);
-                for (int k = 0; k < 9; ++k) S.best[k] = Hr[k];
-            }
+            S.ni = ni;
         }
         S.ok = 1;
     }
+    __syncthreads();
+    if (S.ni > 0 && lm_iters > 0) lm_refine_block(S, S.ni, lm_iters);
     __syncthreads();
 }
 
@@ -393,7 +560,7 @@ struct PostShared {
     double H[9]; int H_ok;
 };
 
-struct PostArgs { const ArgmaxPart* parts; PostParams pp; EagleFrameResult* out; };
+struct PostArgs { const ArgmaxPart* parts; PostParams pp; EagleFrameResult* out; const unsigned* rng_raw; };
 
 __device__ __forceinline__ void persp(const double* H, float fx, float fy, float* ox, float* oy)
 {
@@ -526,7 +693,7 @@ __global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
     __syncthreads();
 
     // (5) homography
-    find_homography_block(S.hs, S.img, S.world, S.npts, pp.ransac_thresh, pp.ransac_max_iters, pp.lm_iters);
+    find_homography_block(S.hs, a.rng_raw, S.img, S.world, S.npts, pp.ransac_thresh, pp.ransac_max_iters, pp.lm_iters);
     __syncthreads();
     const bool Hok = S.npts >= 4 && S.hs.ok;
     if (tid == 0) {
@@ -569,9 +736,27 @@ __global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
     }
 }
 
+// cv::RNG(-1) multiply-with-carry stream, generated once per process and device (never freed)
+static const unsigned* ransac_rng_table()
+{
+    static const unsigned* tab[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (!tab[dev]) {
+        std::vector<unsigned> h(RNG_N);
+        unsigned long long st = 0xffffffffffffffffULL;
+        for (int i = 0; i < RNG_N; ++i) { st = (unsigned long long)(unsigned)st * 4164903690ULL + (unsigned)(st >> 32); h[i] = (unsigned)st; }
+        unsigned* d = nullptr;
+        HIP_CHECK(hipMalloc((void**)&d, sizeof(unsigned) * RNG_N));
+        HIP_CHECK(hipMemcpy(d, h.data(), sizeof(unsigned) * RNG_N, hipMemcpyHostToDevice));
+        tab[dev] = d;
+    }
+    return tab[dev];
+}
+
 void post_launch(const ArgmaxPart* parts, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s)
 {
-    PostArgs a; a.parts = parts; a.pp = pp; a.out = d_out;
+    PostArgs a; a.parts = parts; a.pp = pp; a.out = d_out; a.rng_raw = ransac_rng_table();
     static bool done = false;
     if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PostShared))); done = true; }
     hipLaunchKernelGGL(post_kernel, dim3(n), dim3(POST_T), sizeof(PostShared), s, a);
@@ -579,12 +764,12 @@ void post_launch(const ArgmaxPart* parts, int n, const PostParams& pp, EagleFram
 }
 
 // operator-level entry for the parity tests: findHomography only
-struct HomoArgs { const float* img; const float* world; int n; double thresh; int max_iters, lm_iters; double* H; uint8_t* mask; int* ok; };
+struct HomoArgs { const float* img; const float* world; int n; double thresh; int max_iters, lm_iters; double* H; uint8_t* mask; int* ok; const unsigned* rng_raw; };
 __global__ __launch_bounds__(POST_T) void homography_kernel(HomoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     HomoShared& S = *(HomoShared*)smem;
-    find_homography_block(S, a.img, a.world, a.n, a.thresh, a.max_iters, a.lm_iters);
+    find_homography_block(S, a.rng_raw, a.img, a.world, a.n, a.thresh, a.max_iters, a.lm_iters);
     __syncthreads();
     const bool ok = a.n >= 4 && S.ok;
     if (threadIdx.x == 0) { *a.ok = ok; for (int k = 0; k < 9; ++k) a.H[k] = ok ? S.best[k] : 0.0; }
@@ -593,7 +778,7 @@ __global__ __launch_bounds__(POST_T) void homography_kernel(HomoArgs a)
 void homography_only_launch(const float* d_img, const float* d_world, int npts, double thresh, int max_iters, int lm_iters,
                             double* d_H, uint8_t* d_mask, int* d_ok, hipStream_t s)
 {
-    HomoArgs a{d_img, d_world, npts, thresh, max_iters, lm_iters, d_H, d_mask, d_ok};
+    HomoArgs a{d_img, d_world, npts, thresh, max_iters, lm_iters, d_H, d_mask, d_ok, ransac_rng_table()};
     static bool done = false;
     if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)homography_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HomoShared))); done = true; }
     hipLaunchKernelGGL(homography_kernel, dim3(1), dim3(POST_T), sizeof(HomoShared), s, a);

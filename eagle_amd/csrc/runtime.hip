@@ -79,23 +79,27 @@ struct EagleHandle {
     std::map<std::string, HostTensor> weights;
     bool finalized = false;
     int prec = 0;
-    hipStream_t s_main = nullptr, s_det = nullptr;
+    hipStream_t s_main = nullptr, s_det = nullptr, s_post = nullptr;
     hipEvent_t ev_pre = nullptr, ev_det = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    // two-deep software pipeline: geometry + record D2H of batch i overlap the networks of batch i+1
+    struct StepBuf {
+        ArgmaxPart* parts = nullptr;
+        EagleFrameResult* d_out = nullptr;
+        EagleFrameResult* h_out = nullptr;   // pinned
+        uint8_t* d_frames = nullptr;         // staging copy of the batch (stable pointer for the captured graph)
+        hipEvent_t ev_compute = nullptr, ev_done = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        const uint8_t* g_src = nullptr; int g_n = 0;
+    } sb[2];
     std::unique_ptr<Net> hr, yo, misc;
     // step buffers
-    uint8_t* d_frames = nullptr;          // [batch,h,w,3] staging for host-fed frames
     TView kp_in, det_in, logits;
     LetterBox lb;
-    ArgmaxPart* d_parts = nullptr;
     int hm_chunks = 64;
     DetScratch ds;
     DetLevel levels[3];
-    EagleFrameResult* d_out = nullptr;
-    EagleFrameResult* h_out = nullptr;    // pinned
     PostParams pp;
-    // graph
-    hipGraphExec_t gexec = nullptr;
-    const uint8_t* g_src = nullptr; int g_n = 0; bool warmed = false;
+    bool warmed = false;
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> conv_ev;
@@ -431,65 +435,68 @@ static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
     }
 }
 
-// enqueue one batch step reading frames from d_src (device, dense [n,h,w,3])
-static void enqueue_step(EagleHandle* h, const uint8_t* d_src, int n_active)
+// networks + decode/NMS + heat-map maxima of one batch (buffers of parity p), reading frames from d_src (device)
+static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_active)
 {
     const EagleConfig& c = h->cfg;
     const int B = c.batch;
+    EagleHandle::StepBuf& sb = h->sb[p];
     size_t ev_i = 0;
-    HIP_CHECK(hipMemsetAsync(h->d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
-    TView kp = h->kp_in, det = h->det_in;
-    preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, kp, det, h->lb, h->s_main);
-    const bool two = h->s_det != h->s_main && !h->prof;
+    HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
+    preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
+    const bool two = !h->prof;
     hipStream_t sd = two ? h->s_det : h->s_main;
     if (two) {
         HIP_CHECK(hipEventRecord(h->ev_pre, h->s_main));
         HIP_CHECK(hipStreamWaitEvent(sd, h->ev_pre, 0));
     }
-    // detector branch
-    run_net(h, h->yo.get(), sd, ev_i);
+    run_net(h, h->yo.get(), sd, ev_i);                                   // detector branch
     yolo_decode_launch(h->levels, 3, B, 5, c.detector_floor, h->ds, sd);
-    nms_launch(h->ds, B, h->pp, h->d_out, sd);
+    nms_launch(h->ds, B, h->pp, sb.d_out, sd);
     if (two) HIP_CHECK(hipEventRecord(h->ev_det, sd));
-    // keypoint branch
-    run_net(h, h->hr.get(), h->s_main, ev_i);
-    heat_argmax_launch(h->logits, h->d_parts, h->hm_chunks, h->s_main);
-    if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));
-    post_launch(h->d_parts, B, h->pp, h->d_out, h->s_main);
+    run_net(h, h->hr.get(), h->s_main, ev_i);                            // keypoint branch
+    heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
+    if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));     // join
 }
 
-static void run_step(EagleHandle* h, const uint8_t* d_src, int n_active, EagleFrameResult* out)
+static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_active)
 {
     const EagleConfig& c = h->cfg;
-    HIP_CHECK(hipEventRecord(h->ev_t0, h->s_main));
+    EagleHandle::StepBuf& sb = h->sb[p];
     if (c.use_graph && !h->prof) {
         if (!h->warmed) {   // first call eager: lets every launcher set its function attributes outside a capture
-            enqueue_step(h, d_src, n_active);
+            enqueue_compute(h, p, d_src, n_active);
             HIP_CHECK(hipStreamSynchronize(h->s_main));
-            HIP_CHECK(hipStreamSynchronize(h->s_det));
             h->warmed = true;
         }
-        if (!h->gexec || h->g_src != d_src || h->g_n != n_active) {
-            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        if (!sb.gexec || sb.g_src != d_src || sb.g_n != n_active) {
+            if (sb.gexec) { (void)hipGraphExecDestroy(sb.gexec); sb.gexec = nullptr; }
             hipGraph_t g = nullptr;
             HIP_CHECK(hipStreamBeginCapture(h->s_main, hipStreamCaptureModeGlobal));
-            enqueue_step(h, d_src, n_active);
+            enqueue_compute(h, p, d_src, n_active);
             HIP_CHECK(hipStreamEndCapture(h->s_main, &g));
-            HIP_CHECK(hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphInstantiate(&sb.gexec, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            h->g_src = d_src; h->g_n = n_active;
+            sb.g_src = d_src; sb.g_n = n_active;
         }
-        HIP_CHECK(hipGraphLaunch(h->gexec, h->s_main));
+        HIP_CHECK(hipGraphLaunch(sb.gexec, h->s_main));
     } else {
-        enqueue_step(h, d_src, n_active);
+        enqueue_compute(h, p, d_src, n_active);
     }
-    HIP_CHECK(hipMemcpyAsync(h->h_out, h->d_out, sizeof(EagleFrameResult) * n_active, hipMemcpyDeviceToHost, h->s_main));
-    HIP_CHECK(hipEventRecord(h->ev_t1, h->s_main));
-    HIP_CHECK(hipStreamSynchronize(h->s_main));
-    memcpy(out, h->h_out, sizeof(EagleFrameResult) * n_active);
-    float ms = 0.f;
-    HIP_CHECK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
-    h->timings.total_ms += ms;
+    hipStream_t sp = h->prof ? h->s_main : h->s_post;
+    if (!h->prof) {
+        HIP_CHECK(hipEventRecord(sb.ev_compute, h->s_main));
+        HIP_CHECK(hipStreamWaitEvent(sp, sb.ev_compute, 0));
+    }
+    post_launch(sb.parts, c.batch, h->pp, sb.d_out, sp);
+    HIP_CHECK(hipMemcpyAsync(sb.h_out, sb.d_out, sizeof(EagleFrameResult) * n_active, hipMemcpyDeviceToHost, sp));
+    HIP_CHECK(hipEventRecord(sb.ev_done, sp));
+}
+
+static void collect_step(EagleHandle* h, int p, int n_active, EagleFrameResult* out)
+{
+    HIP_CHECK(hipEventSynchronize(h->sb[p].ev_done));
+    memcpy(out, h->sb[p].h_out, sizeof(EagleFrameResult) * n_active);
     h->timings.n_launches += h->n_launch;
     h->timings.n_conv_launches += h->n_conv;
     h->timings.conv_flop += h->conv_flop_step;
@@ -500,6 +507,31 @@ static void run_step(EagleHandle* h, const uint8_t* d_src, int n_active, EagleFr
             h->timings.conv_ms += t;
         }
     }
+}
+
+// all batches of one call; src_of(i) yields the device pointer of batch i's frames (after any staging copy)
+template <class Stage>
+static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage stage)
+{
+    const int B = h->cfg.batch;
+    memset(&h->timings, 0, sizeof(h->timings));
+    HIP_CHECK(hipEventRecord(h->ev_t0, h->s_main));
+    int prev_n = 0, prev_i = 0, k = 0;
+    for (int i = 0; i < n; i += B, ++k) {
+        const int p = k & 1, na = std::min(B, n - i);
+        const uint8_t* src = stage(p, i, na);
+        launch_step(h, p, src, na);
+        if (k > 0) collect_step(h, p ^ 1, prev_n, out + prev_i);
+        prev_n = na; prev_i = i;
+        if (h->prof) { collect_step(h, p, na, out + i); prev_n = 0; }     // profiling mode: strictly serial
+    }
+    if (prev_n > 0) collect_step(h, (k - 1) & 1, prev_n, out + prev_i);
+    hipStream_t sp = h->prof ? h->s_main : h->s_post;
+    HIP_CHECK(hipEventRecord(h->ev_t1, sp));
+    HIP_CHECK(hipEventSynchronize(h->ev_t1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+    h->timings.total_ms = ms;
 }
 
 static void finalize(EagleHandle* h)
@@ -519,8 +551,14 @@ static void finalize(EagleHandle* h)
     build_yolo(By, h->det_in, c.det_variant, h->levels, 5);
     // scratch
     Net* m = h->misc.get();
-    h->d_frames = (uint8_t*)m->get((size_t)B * c.frame_h * c.frame_w * 3);
-    h->d_parts = (ArgmaxPart*)m->get(sizeof(ArgmaxPart) * (size_t)B * h->hm_chunks * 64);
+    for (auto& sb : h->sb) {
+        sb.d_frames = (uint8_t*)m->get((size_t)B * c.frame_h * c.frame_w * 3);
+        sb.parts = (ArgmaxPart*)m->get(sizeof(ArgmaxPart) * (size_t)B * h->hm_chunks * 64);
+        sb.d_out = (EagleFrameResult*)m->get(sizeof(EagleFrameResult) * (size_t)B);
+        HIP_CHECK(hipHostMalloc((void**)&sb.h_out, sizeof(EagleFrameResult) * (size_t)B, hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&sb.ev_compute, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sb.ev_done, hipEventDisableTiming));
+    }
     int A = 0;
     for (int l = 0; l < 3; ++l) A += h->levels[l].gh * h->levels[l].gw;
     h->ds.A = A;
@@ -529,8 +567,6 @@ static void finalize(EagleHandle* h)
     h->ds.cls = (int*)m->get(sizeof(int) * (size_t)B * A);
     h->ds.keys = (unsigned long long*)m->get(sizeof(unsigned long long) * (size_t)B * A);
     h->ds.count = (int*)m->get(sizeof(int) * (size_t)B);
-    h->d_out = (EagleFrameResult*)m->get(sizeof(EagleFrameResult) * (size_t)B);
-    HIP_CHECK(hipHostMalloc((void**)&h->h_out, sizeof(EagleFrameResult) * (size_t)B, hipHostMallocDefault));
     PostParams& pp = h->pp;
     pp.frame_h = c.frame_h; pp.frame_w = c.frame_w; pp.in_h = h->lb.out_h; pp.in_w = h->lb.out_w;
     pp.hm_h = h->logits.h; pp.hm_w = h->logits.w; pp.hm_chunks = h->hm_chunks;
@@ -594,6 +630,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     nh->cfg = *cfg;
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_main, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_det, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&nh->s_post, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_pre, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_det, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&nh->ev_t0));
@@ -607,12 +644,17 @@ void eagle_destroy(EagleHandle* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (auto& sb : h->sb) {
+        if (sb.gexec) (void)hipGraphExecDestroy(sb.gexec);
+        if (sb.h_out) (void)hipHostFree(sb.h_out);
+        if (sb.ev_compute) (void)hipEventDestroy(sb.ev_compute);
+        if (sb.ev_done) (void)hipEventDestroy(sb.ev_done);
+    }
     for (auto& e : h->conv_ev) (void)hipEventDestroy(e);
-    if (h->h_out) (void)hipHostFree(h->h_out);
     h->hr.reset(); h->yo.reset(); h->misc.reset();
     if (h->s_main) (void)hipStreamDestroy(h->s_main);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
+    if (h->s_post) (void)hipStreamDestroy(h->s_post);
     for (hipEvent_t e : {h->ev_pre, h->ev_det, h->ev_t0, h->ev_t1}) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -650,12 +692,14 @@ int eagle_process_device_frames(EagleHandle* h, const void* d_bgr, int n, EagleF
     if (!h->finalized) fail(EAGLE_E_STATE, "eagle_finalize_weights has not been called");
     if (!d_bgr || !out || n < 0) fail(EAGLE_E_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(h->cfg.device));
-    memset(&h->timings, 0, sizeof(h->timings));
     const size_t fsz = (size_t)h->cfg.frame_h * h->cfg.frame_w * 3;
-    for (int i = 0; i < n; i += h->cfg.batch) {
-        const int na = std::min(h->cfg.batch, n - i);
-        run_step(h, (const uint8_t*)d_bgr + (size_t)i * fsz, na, out + i);
-    }
+    const bool direct = n <= h->cfg.batch || !h->cfg.use_graph;   // a multi-batch clip under graph replay goes through the
+    run_pipeline(h, n, out, [&](int p, int i, int na) -> const uint8_t* {   // stable staging pointer of its parity
+        const uint8_t* src = (const uint8_t*)d_bgr + (size_t)i * fsz;
+        if (direct) return src;
+        HIP_CHECK(hipMemcpyAsync(h->sb[p].d_frames, src, fsz * na, hipMemcpyDeviceToDevice, h->s_main));
+        return h->sb[p].d_frames;
+    });
     API_END(h)
 }
 
@@ -666,18 +710,16 @@ int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t fram
     if (!h->finalized) fail(EAGLE_E_STATE, "eagle_finalize_weights has not been called");
     if (!bgr || !out || n < 0) fail(EAGLE_E_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(h->cfg.device));
-    memset(&h->timings, 0, sizeof(h->timings));
     const int fh = h->cfg.frame_h, fw = h->cfg.frame_w;
     const size_t fsz = (size_t)fh * fw * 3;
     if (row_stride == 0) row_stride = (int64_t)fw * 3;
     if (frame_stride == 0) frame_stride = row_stride * fh;
-    for (int i = 0; i < n; i += h->cfg.batch) {
-        const int na = std::min(h->cfg.batch, n - i);
+    run_pipeline(h, n, out, [&](int p, int i, int na) -> const uint8_t* {
         for (int k = 0; k < na; ++k)
-            HIP_CHECK(hipMemcpy2DAsync(h->d_frames + (size_t)k * fsz, (size_t)fw * 3, bgr + (size_t)(i + k) * frame_stride,
+            HIP_CHECK(hipMemcpy2DAsync(h->sb[p].d_frames + (size_t)k * fsz, (size_t)fw * 3, bgr + (size_t)(i + k) * frame_stride,
                                        (size_t)row_stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, h->s_main));
-        run_step(h, h->d_frames, na, out + i);
-    }
+        return h->sb[p].d_frames;
+    });
     API_END(h)
 }
 

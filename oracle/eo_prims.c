@@ -284,38 +284,44 @@ void eo_fit_line_l2(const float* pts, int n, float* line)
 /* ---------------------------------------------------------------------------------------------------- */
 /* cv2.findHomography(src, dst, RANSAC, 5.0) (coordinate_model.py:355). PARITY UNPINNED. */
 /* ---------------------------------------------------------------------------------------------------- */
-/* symmetric 9x9 eigen-solve by cyclic Jacobi in float64; returns eigenvector of the smallest eigenvalue. */
-static void eo_jacobi9_smallest(double A[9][9], double v[9])
+/* symmetric 9x9 eigen-solve in float64: classic cyclic Jacobi on the UPPER triangle (diagonal kept in d[], rotations
+ * in the tau form, small off-diagonals zeroed after 4 sweeps); returns the eigenvector of the smallest eigenvalue.
+ * cv::eigen uses a max-pivot Jacobi; both converge to the same eigenvector to ~1e-15.  The HIP kernel
+ * (eagle_amd/csrc/geom.hip::jacobi9_smallest) performs exactly these operations in exactly this order. */
+#define EO_ROT(x, y) do { const double g_ = (x), h_ = (y); (x) = g_ - s * (h_ + g_ * tau); (y) = h_ + s * (g_ - h_ * tau); } while (0)
+static void eo_jacobi9_smallest(double a[9][9], double v[9])
 {
-    double V[9][9];
-    for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int p = 0; p < 8; ++p) for (int q = p + 1; q < 9; ++q) off += A[p][q] * A[p][q];
-        if (off < 1e-300) break;
+    double V[9][9], d[9], b[9], z[9];
+    for (int i = 0; i < 9; ++i) { for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0; d[i] = b[i] = a[i][i]; z[i] = 0.0; }
+    for (int sweep = 1; sweep <= 50; ++sweep) {
+        double sm = 0.0;
+        for (int p = 0; p < 8; ++p) for (int q = p + 1; q < 9; ++q) sm += fabs(a[p][q]);
+        if (sm == 0.0) break;
+        const double tresh = sweep < 4 ? 0.2 * sm / 81.0 : 0.0;
         for (int p = 0; p < 8; ++p)
             for (int q = p + 1; q < 9; ++q) {
-                const double apq = A[p][q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 9; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+                const double g = 100.0 * fabs(a[p][q]);
+                if (sweep > 4 && fabs(d[p]) + g == fabs(d[p]) && fabs(d[q]) + g == fabs(d[q])) { a[p][q] = 0.0; continue; }
+                if (!(fabs(a[p][q]) > tresh)) continue;
+                double h = d[q] - d[p], t;
+                if (fabs(h) + g == fabs(h)) t = a[p][q] / h;
+                else {
+                    const double theta = 0.5 * h / a[p][q];
+                    t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                    if (theta < 0.0) t = -t;
                 }
-                for (int k = 0; k < 9; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 9; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
-                }
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c);
+                h = t * a[p][q];
+                z[p] -= h; z[q] += h; d[p] -= h; d[q] += h; a[p][q] = 0.0;
+                for (int j = 0; j < p; ++j) EO_ROT(a[j][p], a[j][q]);
+                for (int j = p + 1; j < q; ++j) EO_ROT(a[p][j], a[j][q]);
+                for (int j = q + 1; j < 9; ++j) EO_ROT(a[p][j], a[q][j]);
+                for (int j = 0; j < 9; ++j) EO_ROT(V[j][p], V[j][q]);
             }
+        for (int i = 0; i < 9; ++i) { b[i] += z[i]; d[i] = b[i]; z[i] = 0.0; }
     }
     int m = 0;
-    for (int i = 1; i < 9; ++i) if (A[i][i] < A[m][m]) m = i;
+    for (int i = 1; i < 9; ++i) if (d[i] < d[m]) m = i;
     for (int k = 0; k < 9; ++k) v[k] = V[k][m];
 }
 
@@ -350,6 +356,63 @@ int eo_dlt_homography(const double* src, const double* dst, const int* sel, int 
     double h[9];
     eo_jacobi9_smallest(LtL, h);
     /* H = inv(T_dst) * H0 * T_src,  T = [[s0,0,-c0*s0],[0,s1,-c1*s1],[0,0,1]] */
+    const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double t[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += iT[3 * r + k] * h[3 * k + c]; t[3 * r + c] = s; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += t[3 * r + k] * T[3 * k + c]; H[3 * r + c] = s; }
+    if (fabs(H[8]) < 2.220446049250313e-16) return 0;
+    const double inv = 1.0 / H[8];
+    for (int k = 0; k < 9; ++k) H[k] *= inv;
+    H[8] = 1.0;
+    return 1;
+}
+
+/* Minimal-sample (4 correspondences) model of the RANSAC hypothesis stage.  cv2's runKernel takes the null vector of the
+ * 9x9 LtL also for 4 points; the 8 equations determine H up to scale, so the same H is obtained by fixing h33 = 1 in the
+ * NORMALISED frame and solving the 8x8 system by Gaussian elimination with partial pivoting (fails only when the normalised
+ * h33 vanishes).  This is what eagle_amd/csrc/geom.hip::h4_homography computes, operation for operation.  The final fit on
+ * all inliers still goes through eo_dlt_homography (LtL eigen-solve) + LM like cv2. */
+int eo_h4_homography(const double* src, const double* dst, const int* idx, double* H)
+{
+    const int n = 4;
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = 0; i < n; ++i) { const int k = idx[i]; cM[0] += src[2 * k]; cM[1] += src[2 * k + 1]; cm[0] += dst[2 * k]; cm[1] += dst[2 * k + 1]; }
+    cM[0] /= n; cM[1] /= n; cm[0] /= n; cm[1] /= n;
+    for (int i = 0; i < n; ++i) {
+        const int k = idx[i];
+        sM[0] += fabs(src[2 * k] - cM[0]); sM[1] += fabs(src[2 * k + 1] - cM[1]);
+        sm[0] += fabs(dst[2 * k] - cm[0]); sm[1] += fabs(dst[2 * k + 1] - cm[1]);
+    }
+    if (fabs(sM[0]) < 2.220446049250313e-16 || fabs(sM[1]) < 2.220446049250313e-16 ||
+        fabs(sm[0]) < 2.220446049250313e-16 || fabs(sm[1]) < 2.220446049250313e-16) return 0;
+    sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
+    double M[8][9];
+    for (int i = 0; i < n; ++i) {
+        const int k = idx[i];
+        const double X = (src[2 * k] - cM[0]) * sM[0], Y = (src[2 * k + 1] - cM[1]) * sM[1];
+        const double x = (dst[2 * k] - cm[0]) * sm[0], y = (dst[2 * k + 1] - cm[1]) * sm[1];
+        double* a = M[2 * i]; double* b = M[2 * i + 1];
+        a[0] = X; a[1] = Y; a[2] = 1; a[3] = 0; a[4] = 0; a[5] = 0; a[6] = -x * X; a[7] = -x * Y; a[8] = x;
+        b[0] = 0; b[1] = 0; b[2] = 0; b[3] = X; b[4] = Y; b[5] = 1; b[6] = -y * X; b[7] = -y * Y; b[8] = y;
+    }
+    for (int c = 0; c < 8; ++c) {
+        int p = c; double best = fabs(M[c][c]);
+        for (int r = c + 1; r < 8; ++r) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
+        if (best < 1e-13) return 0;
+        if (p != c) for (int j = c; j < 9; ++j) { const double t = M[c][j]; M[c][j] = M[p][j]; M[p][j] = t; }
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = M[r][c] / M[c][c];
+            for (int j = c + 1; j < 9; ++j) M[r][j] = M[r][j] - f * M[c][j];
+        }
+    }
+    double h[9];
+    for (int i = 7; i >= 0; --i) {
+        double s = M[i][8];
+        for (int j = i + 1; j < 8; ++j) s = s - M[i][j] * h[j];
+        h[i] = s / M[i][i];
+    }
+    h[8] = 1.0;
     const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
     const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
     double t[9];
@@ -409,6 +472,12 @@ static uint32_t eo_rng_next(uint64_t* st)
 {
     *st = (uint64_t)(uint32_t)(*st) * 4164903690ULL + (uint32_t)(*st >> 32);
     return (uint32_t)(*st);
+}
+
+void eo_rng_stream(uint32_t* out, int n)
+{
+    uint64_t st = 0xffffffffffffffffULL;
+    for (int i = 0; i < n; ++i) out[i] = eo_rng_next(&st);
 }
 
 static int eo_ransac_update_iters(double p, double ep, int model_points, int max_iters)
@@ -541,7 +610,7 @@ int eo_find_homography_ransac(const float* srcf, const float* dstf, int n, doubl
             }
             if (!found) { if (iter == 0) { ok = 0; goto done; } break; }
             double Hc[9];
-            if (!eo_dlt_homography(src, dst, idx, 4, Hc)) continue;
+            if (!eo_h4_homography(src, dst, idx, Hc)) continue;
             eo_reproj_err(src, dst, n, Hc, err);
             int good = 0;
             for (int i = 0; i < n; ++i) { m[i] = err[i] <= t2; good += m[i]; }

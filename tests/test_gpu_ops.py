@@ -100,7 +100,7 @@ def _camera_points(seed, noise=0.0, n_out=0):
     return img.astype(np.float32), world.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed,noise,n_out", [(0, 0.0, 0), (1, 0.7, 0), (2, 0.5, 4), (3, 1.0, 7), (4, 0.0, 2)])
+@pytest.mark.parametrize("seed,noise,n_out", [(0, 0.0, 0), (1, 0.7, 0), (2, 0.5, 4), (3, 1.0, 7), (4, 0.0, 2), (5, 2.0, 14), (6, 0.3, 18)])
 def test_find_homography_bit_exact(seed, noise, n_out):
     from eagle_amd import lib
     from oracle import prims as P
@@ -118,3 +118,19 @@ def test_find_homography_degenerate():
     pts = np.array([[0, 0], [1, 1], [2, 2], [3, 3], [4, 4]], np.float32)
     assert lib.op_find_homography(pts, pts)[0] is None          # collinear: no valid subset
     assert lib.op_find_homography(pts[:3], pts[:3])[0] is None  # fewer than 4 points
+
+
+@pytest.mark.parametrize("seed,n", [(0, 5), (1, 9), (2, 30), (3, 57), (4, 87)])
+def test_find_homography_garbage_points_full_2000_iterations(seed, n):
+    """Geometrically meaningless correspondences (what random-weight heat-maps give): RANSAC runs to its iteration cap,
+    through several parallel rounds of the precomputed cv::RNG stream; still bit-identical to the sequential oracle."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    rng = np.random.default_rng(100 + seed)
+    img = np.floor(rng.uniform(0, 1280, (n, 2))).astype(np.float32)
+    world = rng.uniform(0, 105, (n, 2)).astype(np.float32)
+    H0, m0 = P.find_homography_ransac(img, world, 5.0)
+    H1, m1 = lib.op_find_homography(img, world, 5.0)
+    assert (H0 is None) == (H1 is None)
+    if H0 is not None:
+        assert np.array_equal(m0, m1) and np.array_equal(H0, H1)

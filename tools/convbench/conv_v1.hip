@@ -13,10 +13,8 @@
 //   * fp32 family: v_mfma_f32_16x16x4_f32 in the canonical K order (16-channel chunk, tap, channel): gfx950
 //     accumulates these as a k-ordered fmaf chain, so outputs are bit-identical to oracle/eo_prims.c.
 // Epilogue: v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); store (fp16 RNE / fp32).
-#include <algorithm>
-
-#include "common.h"
-#include "dmath.h"
+#include "../../eagle_amd/csrc/common.h"
+#include "../../eagle_amd/csrc/dmath.h"
 
 namespace eagle {
 
@@ -42,12 +40,8 @@ template <int KC> struct F16Geom {
     static constexpr int PS = KC * 2 + ((G % 2 == 0) ? 16 : 0);        // LDS pixel stride (bytes), odd in 16-B units
 };
 
-// One workgroup per (output tile, Cout block).  Per Cin-chunk every thread first ISSUES all of its 16-byte global loads
-// (weight slice + halo tile) back to back into registers and only then writes them to LDS, so a chunk costs one memory
-// round trip instead of one per staging iteration; tile shapes are chosen so that two workgroups share a CU (LDS <= 80 KiB,
-// <= 256 VGPRs) and one workgroup's MFMAs hide the other's staging.
 template <int KS, int S, int KC, int NT>
-__global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
+__global__ __launch_bounds__(256) void conv_f16_kernel(ConvArgs a)
 {
     constexpr int G = F16Geom<KC>::G;
     constexpr int PS = F16Geom<KC>::PS;
@@ -99,34 +93,19 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     const int ngroups = halo_h * halo_w * G;
 
     for (int ch = 0; ch < a.nchunks; ++ch) {
-        {
-            constexpr int MAXPIX = (KS == 1) ? 256 : ((S == 1) ? 340 : 1105);
-            constexpr int NPA = (MAXPIX * G + 255) / 256;
-            constexpr int NPW = (WBYTES / 16 + 255) / 256;
-            uint4 pa[NPA], pw[NPW];
+        {   // weights of this (nb, chunk): one contiguous pre-tiled image
             const char* wsrc = (const char*)a.w + (size_t)(nb * a.nchunks + ch) * WBYTES;
-            const int c0 = a.xoff + ch * KC;
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; pw[i] = *(const uint4*)(wsrc + (o < WBYTES ? o : 0)); }
-#pragma unroll
-            for (int i = 0; i < NPA; ++i) {
-                const int idx = tid + 256 * i;
-                const int pix = idx / G, g = idx - pix * G;
-                const int hy = pix / halo_w, hx = pix - hy * halo_w;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (idx < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                    v = *(const uint4*)(xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0 + g * 8);
-                pa[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; if (o < WBYTES) *(uint4*)(lds_w + o) = pw[i]; }
-#pragma unroll
-            for (int i = 0; i < NPA; ++i) {
-                const int idx = tid + 256 * i;
-                const int pix = idx / G, g = idx - pix * G;
-                if (idx < ngroups) *(uint4*)(lds_a + pix * PS + g * 16) = pa[i];
-            }
+            for (int o = tid * 16; o < WBYTES; o += 256 * 16) *(uint4*)(lds_w + o) = *(const uint4*)(wsrc + o);
+        }
+        const int c0 = a.xoff + ch * KC;
+        for (int idx = tid; idx < ngroups; idx += 256) {
+            const int pix = idx / G, g = idx - pix * G;
+            const int hy = pix / halo_w, hx = pix - hy * halo_w;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *(const uint4*)(xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0 + g * 8);
+            *(uint4*)(lds_a + pix * PS + g * 16) = v;
         }
         __syncthreads();
 #pragma unroll
@@ -335,29 +314,24 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
 {
     ConvConfig c;
     c.ks = ks; c.stride = stride; c.cin = cin_pad; c.cout_pad = cout_pad;
-    c.wx = (wo > 16) ? 2 : 1;
     static const int nts[] = {6, 4, 3, 2, 1};
+    c.nt = 1;
+    for (int nt : nts)
+        if (cout_pad % (16 * nt) == 0) { c.nt = nt; break; }
+    c.wx = (wo > 16) ? 2 : 1;
     if (precision == EAGLE_PREC_F32) {
-        c.nt = 1;
-        for (int nt : nts)
-            if (cout_pad % (16 * nt) == 0) { c.nt = nt; break; }
         c.kc = (cin_pad < 16) ? 4 : 16;
         return c;
     }
-    // fp16: the (NT, KC) pair with the most work per staged item whose LDS footprint still lets two workgroups share a CU
+    const int bn = c.nt * 16;
     static const int kcs[] = {64, 48, 32, 16, 8};
-    long best = -1;
-    c.nt = 1; c.kc = 8;
-    for (int nt : nts) {
-        if (cout_pad % (16 * nt)) continue;
-        for (int kc : kcs) {
-            if (cin_pad % kc) continue;
-            ConvConfig t = c; t.nt = nt; t.kc = kc;
-            if (!find_inst(precision, t)) continue;
-            if (lds_bytes(precision, t) > 80 * 1024) continue;
-            const long score = (long)kc * nt * 1000 + kc;
-            if (score > best) { best = score; c.nt = nt; c.kc = kc; }
-        }
+    c.kc = 8;
+    for (int kc : kcs) {
+        if (cin_pad % kc) continue;
+        if (stride == 2 && kc > 16) continue;
+        if (ks == 3 && kc * bn > 3072) continue;
+        c.kc = kc;
+        break;
     }
     return c;
 }

@@ -15,8 +15,8 @@
 // Epilogue: v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); store (fp16 RNE / fp32).
 #include <algorithm>
 
-#include "common.h"
-#include "dmath.h"
+#include "../../eagle_amd/csrc/common.h"
+#include "../../eagle_amd/csrc/dmath.h"
 
 namespace eagle {
 
@@ -42,12 +42,15 @@ template <int KC> struct F16Geom {
     static constexpr int PS = KC * 2 + ((G % 2 == 0) ? 16 : 0);        // LDS pixel stride (bytes), odd in 16-B units
 };
 
-// One workgroup per (output tile, Cout block).  Per Cin-chunk every thread first ISSUES all of its 16-byte global loads
-// (weight slice + halo tile) back to back into registers and only then writes them to LDS, so a chunk costs one memory
-// round trip instead of one per staging iteration; tile shapes are chosen so that two workgroups share a CU (LDS <= 80 KiB,
-// <= 256 VGPRs) and one workgroup's MFMAs hide the other's staging.
+// Persistent workgroups: gridDim.x workgroups walk the (tile, Cin-chunk) items of one Cout block.  While the MFMAs of
+// item i run out of LDS, the halo tile (and, for multi-chunk layers, the weight slice) of item i+1 is already in flight
+// into registers; it is written to LDS after the barrier that ends item i.  Single-chunk layers (e.g. 48->48) keep their
+// whole weight tensor resident in LDS for every tile the workgroup processes.
 template <int KS, int S, int KC, int NT>
-__global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
+#ifndef CONV_OCC
+#define CONV_OCC 1
+#endif
+__global__ __launch_bounds__(256, CONV_OCC) void conv_f16_kernel(ConvArgs a)
 {
     constexpr int G = F16Geom<KC>::G;
     constexpr int PS = F16Geom<KC>::PS;
@@ -56,6 +59,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     constexpr int NI = (NGR + 3) / 4;
     constexpr int BN = NT * 16;
     constexpr int WBYTES = NI * 4 * BN * 16;
+    constexpr int MAXPIX = (KS == 1) ? 256 : ((S == 1) ? 340 : 1105);     // largest halo tile over wx in {1,2}
+    constexpr int NPA = (MAXPIX * G + 255) / 256;                         // 16-byte activation groups per thread
+    constexpr int NPW = (WBYTES / 16 + 255) / 256;                        // 16-byte weight groups per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_w = smem;
     char* lds_a = smem + WBYTES;
@@ -63,20 +69,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     const int WX = a.wx, TH = 16 / WX, TW = 16 * WX;
     const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, lx = lane & 15;
-    int t = blockIdx.x;
-    const int tx = t % a.tiles_x; t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int n = t / a.tiles_y;
     const int nb = blockIdx.y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - KS / 2, ix0 = ox0 * S - KS / 2;
+    const int ntiles = a.tiles_x * a.tiles_y * a.N;
+    const int ngroups = halo_h * halo_w * G;
 
-    f32x4 acc[NT][4];
+    // tile-invariant staging slots of this thread
+    int s_lds[NPA], s_gl[NPA], s_yx[NPA];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    for (int i = 0; i < NPA; ++i) {
+        const int idx = tid + 256 * i;
+        const int pix = idx / G, g = idx - pix * G;
+        const int hy = pix / halo_w, hx = pix - hy * halo_w;
+        s_lds[i] = idx < ngroups ? pix * PS + g * 16 : -1;
+        s_gl[i] = (hy * a.W + hx) * a.xcs + g * 8;
+        s_yx[i] = (hy << 16) | hx;
+    }
     int abase[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -96,39 +103,66 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     }
     const int wlane = (q * BN + lx) * 16;
     const _Float16* xg = (const _Float16*)a.x;
-    const int ngroups = halo_h * halo_w * G;
 
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        {
-            constexpr int MAXPIX = (KS == 1) ? 256 : ((S == 1) ? 340 : 1105);
-            constexpr int NPA = (MAXPIX * G + 255) / 256;
-            constexpr int NPW = (WBYTES / 16 + 255) / 256;
-            uint4 pa[NPA], pw[NPW];
-            const char* wsrc = (const char*)a.w + (size_t)(nb * a.nchunks + ch) * WBYTES;
-            const int c0 = a.xoff + ch * KC;
+    f32x4 acc[NT][4];
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; pw[i] = *(const uint4*)(wsrc + (o < WBYTES ? o : 0)); }
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int i = 0; i < NPA; ++i) {
-                const int idx = tid + 256 * i;
-                const int pix = idx / G, g = idx - pix * G;
-                const int hy = pix / halo_w, hx = pix - hy * halo_w;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (idx < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                    v = *(const uint4*)(xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0 + g * 8);
-                pa[i] = v;
-            }
+        for (int p = 0; p < 4; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 pa[NPA], pw[NPW];
+    int t = blockIdx.x, ch = 0;
+    if (t >= ntiles) return;
+    bool wload = true;
+
+#define CONV_TILE_ORIGIN(T_, n_, oy0_, ox0_)                 \
+    int n_, oy0_, ox0_;                                      \
+    {                                                        \
+        int tt_ = (T_);                                      \
+        const int tx_ = tt_ % a.tiles_x; tt_ /= a.tiles_x;   \
+        const int ty_ = tt_ % a.tiles_y;                     \
+        n_ = tt_ / a.tiles_y; oy0_ = ty_ * TH; ox0_ = tx_ * TW; \
+    }
+#define CONV_ISSUE(T_, CH_, WL_)                                                                              \
+    {                                                                                                         \
+        CONV_TILE_ORIGIN(T_, n_i, oy0_i, ox0_i)                                                                \
+        const int iy0 = oy0_i * S - KS / 2, ix0 = ox0_i * S - KS / 2;                                          \
+        const long long base = ((long long)(n_i * a.H + iy0) * a.W + ix0) * a.xcs + a.xoff + (CH_) * KC;       \
+        _Pragma("unroll") for (int i = 0; i < NPA; ++i) {                                                      \
+            const int iy = iy0 + (s_yx[i] >> 16), ix = ix0 + (s_yx[i] & 0xffff);                               \
+            uint4 v = make_uint4(0, 0, 0, 0);                                                                  \
+            if (s_lds[i] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xg + base + s_gl[i]); \
+            pa[i] = v;                                                                                         \
+        }                                                                                                      \
+        if (WL_) {                                                                                             \
+            const char* wsrc = (const char*)a.w + (size_t)(nb * a.nchunks + (CH_)) * WBYTES;                   \
+            _Pragma("unroll") for (int i = 0; i < NPW; ++i) {                                                  \
+                const int o = (tid + 256 * i) * 16;                                                            \
+                pw[i] = *(const uint4*)(wsrc + (o < WBYTES ? o : 0));                                          \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    CONV_ISSUE(t, ch, true)
+    for (;;) {
+        __syncthreads();                               // every wave is done reading LDS for the previous item
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; if (o < WBYTES) *(uint4*)(lds_w + o) = pw[i]; }
+        for (int i = 0; i < NPA; ++i)
+            if (s_lds[i] >= 0) *(uint4*)(lds_a + s_lds[i]) = pa[i];
+        if (wload) {
 #pragma unroll
-            for (int i = 0; i < NPA; ++i) {
-                const int idx = tid + 256 * i;
-                const int pix = idx / G, g = idx - pix * G;
-                if (idx < ngroups) *(uint4*)(lds_a + pix * PS + g * 16) = pa[i];
+            for (int i = 0; i < NPW; ++i) {
+                const int o = (tid + 256 * i) * 16;
+                if (o < WBYTES) *(uint4*)(lds_w + o) = pw[i];
             }
         }
         __syncthreads();
+        int nt_ = t, nch = ch + 1;
+        if (nch == a.nchunks) { nch = 0; nt_ = t + gridDim.x; }
+        const bool has_next = nt_ < ntiles;
+        const bool nwload = a.nchunks > 1;
+        if (has_next) CONV_ISSUE(nt_, nch, nwload)
+
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             half8 wa[NT], xb[4];
@@ -142,43 +176,51 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
                 for (int p = 0; p < 4; ++p)
                     acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
         }
-        __syncthreads();
-    }
 
-    // epilogue: lane holds channels co..co+3 of pixel (oy, ox)
+        if (ch == a.nchunks - 1) {                     // epilogue: lane holds channels co..co+3 of pixel (oy, ox)
+            CONV_TILE_ORIGIN(t, n, oy0, ox0)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
-        const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
-        if (oy >= a.Ho || ox >= a.Wo) continue;
-        const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+            for (int p = 0; p < 4; ++p) {
+                const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+                const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
+                const bool inb = oy < a.Ho && ox < a.Wo;
+                const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const int co = nb * BN + tt * 16 + q * 4;
-            const float4 bv = *(const float4*)(a.bias + co);
-            float v[4] = {acc[tt][p][0] + bv.x, acc[tt][p][1] + bv.y, acc[tt][p][2] + bv.z, acc[tt][p][3] + bv.w};
+                for (int tt = 0; tt < NT; ++tt) {
+                    if (inb) {
+                        const int co = nb * BN + tt * 16 + q * 4;
+                        const float4 bv = *(const float4*)(a.bias + co);
+                        float v[4] = {acc[tt][p][0] + bv.x, acc[tt][p][1] + bv.y, acc[tt][p][2] + bv.z, acc[tt][p][3] + bv.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.pre_act);
-            if (a.r1) {
-                const half4 rv = *(const half4*)((const _Float16*)a.r1 + pidx * a.r1cs + a.r1off + co);
+                        for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.pre_act);
+                        if (a.r1) {
+                            const half4 rv = *(const half4*)((const _Float16*)a.r1 + pidx * a.r1cs + a.r1off + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
-            }
-            if (a.r2) {
-                const half4 rv = *(const half4*)((const _Float16*)a.r2 + pidx * a.r2cs + a.r2off + co);
+                            for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
+                        }
+                        if (a.r2) {
+                            const half4 rv = *(const half4*)((const _Float16*)a.r2 + pidx * a.r2cs + a.r2off + co);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] + (float)rv[r];
-            }
+                            for (int r = 0; r < 4; ++r) v[r] = v[r] + (float)rv[r];
+                        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.post_act);
-            if (a.out_f32) {
-                *(float4*)((float*)a.y + pidx * a.ycs + a.yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *(half4*)((_Float16*)a.y + pidx * a.ycs + a.yoff + co) = o;
+                        for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.post_act);
+                        if (a.out_f32) {
+                            *(float4*)((float*)a.y + pidx * a.ycs + a.yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            *(half4*)((_Float16*)a.y + pidx * a.ycs + a.yoff + co) = o;
+                        }
+                    }
+                    acc[tt][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
+        if (!has_next) break;
+        t = nt_; ch = nch; wload = nwload;
     }
+#undef CONV_ISSUE
+#undef CONV_TILE_ORIGIN
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -354,7 +396,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
             if (cin_pad % kc) continue;
             ConvConfig t = c; t.nt = nt; t.kc = kc;
             if (!find_inst(precision, t)) continue;
-            if (lds_bytes(precision, t) > 80 * 1024) continue;
+            if (lds_bytes(precision, t) > 81 * 1024 + 512) continue;
             const long score = (long)kc * nt * 1000 + kc;
             if (score > best) { best = score; c.nt = nt; c.kc = kc; }
         }
@@ -425,7 +467,10 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         HIP_CHECK(hipFuncSetAttribute((const void*)inst->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[ii] = true;
     }
-    dim3 grid(a.tiles_x * a.tiles_y * a.N, c.cout_pad / (c.nt * 16));
+    const int gy = c.cout_pad / (c.nt * 16);
+    int gx = a.tiles_x * a.tiles_y * a.N;
+    if (precision == EAGLE_PREC_F16) gx = std::min(gx, std::max(1, (256 * 2) / gy));   // persistent: 2 workgroups per CU
+    dim3 grid(gx, gy);
     hipLaunchKernelGGL(inst->fn, grid, dim3(256), lds, s, a);
     HIP_CHECK(hipGetLastError());
 }

@@ -3,7 +3,9 @@
 
 One "step" = one pass of the hot path over one device batch of ``--batch`` synthetic frames that are already
 resident in HBM (C ABI: eagle_process_device_frames).  Default run = BASELINE.json configs[1]: a 1000-frame
-1280x720 synthetic clip, YOLOv8-n detector + HRNet-W48 keypoint model, one MI355X (50 steps x 20 frames).
+1280x720 synthetic clip, YOLOv8-n detector + HRNet-W48 keypoint model, one MI355X (40 steps x 25 frames).
+The K timed steps are issued as ONE library call over the K*batch-frame clip so that the library's two-deep pipeline
+(geometry + record copy of step i under the networks of step i+1) is part of what is measured.
 Multi-GPU (driver launches one rank per GPU through torch.distributed.run): frames shard by contiguous chunk,
 weights replicated, no data-path collective; ONE all-gather of the fixed-size records at the end (inside the timed
 region); value = total frames of all ranks / max-over-ranks time  ("scaling": "weak").
@@ -24,28 +26,47 @@ FLOP_PER_FRAME = 339.0e9          # SURVEY §8d / BASELINE.md §3: 4.85 G (yolov
 MFMA_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 
 
-def cpu_baseline(hs, ys, frames, n_frames, threads):
-    """The oracle's torch-CPU fp32 restatement of S(frame), timed on this host on a bounded sample."""
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(hs, ys, frames, n_frames, threads, budget_s=25.0):
+    """The oracle's torch-CPU fp32 restatement of S(frame), timed on this host on a bounded sample
+    (at most n_frames frames or ~budget_s seconds of CPU work, whichever comes first)."""
     import torch
     torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle import pipeline
     m = pipeline.OracleModel(hs, ys, backend="torch")
-    m.step(frames[0])                                  # warm-up (weight folding, MKLDNN primitives)
     t0 = time.perf_counter()
+    m.step(frames[0])                                  # warm-up (weight folding, MKLDNN primitives)
+    log(f"cpu_baseline warm-up frame {time.perf_counter() - t0:.1f} s ({threads} threads)")
+    t0 = time.perf_counter()
+    done = 0
     for i in range(n_frames):
         m.step(frames[i % len(frames)], i)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
     dt = time.perf_counter() - t0
-    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n_frames} frames of the same synthetic clip through oracle/pipeline.py (torch-CPU fp32 nets + "
-                      f"numpy/C host logic), {threads} threads of {os.cpu_count()} logical CPUs, {dt:.1f} s"}
+    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{done} frames of the same synthetic clip through oracle/pipeline.py (torch-CPU fp32 nets + "
+                      f"numpy/C host logic), {threads} threads ({usable_cpus()} usable of {os.cpu_count()} logical CPUs), {dt:.1f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=20, help="frames per device step")
+    ap.add_argument("--batch", type=int, default=25, help="frames per device step")
     ap.add_argument("--detector", default="n")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--height", type=int, default=720)
@@ -79,6 +100,7 @@ def main():
                    batch=B, precision=lib.PREC_F16 if a.precision == "f16" else lib.PREC_F32,
                    use_graph=0 if a.no_graph else 1)
     weights.load_into(h, [hs, ys])
+    log(f"rank {rank}: handle ready (batch {B})")
     gather_used = a.gather
     if world > 1 and a.gather == "rccl":
         try:
@@ -91,11 +113,13 @@ def main():
         if int(flag.item()):
             gather_used = "dist"
 
-    # this rank's contiguous chunk of the (weak-scaled) clip: (W+K)*B frames per rank, distinct per rank
+    # this rank's contiguous chunk of the (weak-scaled) clip: K*B frames per rank (distinct content per rank), resident in HBM
     n_local = K * B
-    base = synth.clip(seed=rank, n=min(a.distinct, B), h=a.height, w=a.width)
-    frames = np.concatenate([base] * (-(-B // len(base))))[:B]
-    d_frames = h.upload(frames)                       # inputs resident in HBM before the timed region
+    base = synth.clip(seed=rank, n=min(a.distinct, n_local), h=a.height, w=a.width)
+    clip = np.concatenate([base] * (-(-n_local // len(base))))[:n_local]
+    frames = clip[:B]
+    d_clip = h.upload(clip)                           # inputs resident in HBM before the timed region
+    log(f"rank {rank}: {n_local} frames resident in HBM")
     out = np.zeros(n_local, lib.RESULT_DTYPE)
 
     def sync():
@@ -104,12 +128,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(W):
-        h.process_device(d_frames, B, out[:B])
+    if W > 0:
+        h.process_device(d_clip, min(W, K) * B, out[:min(W, K) * B])
     sync()
     t0 = time.perf_counter()
-    for k in range(K):
-        h.process_device(d_frames, B, out[k * B:(k + 1) * B])
+    h.process_device(d_clip, n_local, out)            # K steps of B frames
     if world > 1:
         allrec = shard.gather_records(out, n_local * world, rank, world, handle=h, transport=gather_used)
     else:
@@ -122,6 +145,7 @@ def main():
         dt = float(tt.item())
     total_frames = n_local * world
     assert len(allrec) == total_frames
+    log(f"timed region {dt:.3f} s -> {total_frames / dt:.1f} frames/s")
 
     # dominant kernel = the implicit-GEMM convolution family: per-launch HIP events on the launch stream
     h.set_profiling(1)
@@ -129,7 +153,7 @@ def main():
     conv_ms = conv_flop = 0.0
     n_conv = 0
     for _ in range(prof_steps):
-        h.process_device(d_frames, B, out[:B])
+        h.process_device(d_clip, B, out[:B])
         t = h.timings()
         conv_ms += t.conv_ms; conv_flop += t.conv_flop; n_conv += t.n_conv_launches
     h.set_profiling(0)
@@ -141,7 +165,7 @@ def main():
             "metric": "frames/sec end-to-end (detect+keypoint+homography) @1280x720",
             "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if a.precision == "f16" else "f32", "data": f"synthetic ({len(base)} distinct frames per rank tiled; seeded synthetic weights)",
+            "dtype": "f16" if a.precision == "f16" else "f32", "data": f"synthetic ({len(base)} distinct generated frames per rank tiled to {n_local}; seeded synthetic weights)",
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}",
                        "gather": "none" if world == 1 else gather_used, "hip_graph": not a.no_graph},
@@ -152,8 +176,8 @@ def main():
                          "conv_ms_per_step": round(conv_ms / prof_steps, 3), "traffic": None},
         }
         if not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, os.cpu_count() or 1))
-    h.free(d_frames)
+            res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())))
+    h.free(d_clip)
     h.close()
     if dist is not None:
         dist.barrier()

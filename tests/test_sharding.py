@@ -1,0 +1,88 @@
+"""CPU tests of the N>1 path: contiguous frame sharding + the single end-of-clip gather of fixed-size records,
+run as two real processes over gloo (the GPU box runs the same code over RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from eagle_amd import shard
+from eagle_amd.lib import RESULT_DTYPE
+n_frames = int(sys.argv[2])
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lo, hi = shard.shard_range(n_frames, rank, world)
+local = np.zeros(hi - lo, RESULT_DTYPE)
+for k, f in enumerate(range(lo, hi)):                 # a record that identifies its frame
+    local[k]["n_det"] = f
+    local[k]["n_kp"] = 1000 + f
+    local[k]["H"][:] = np.arange(9) + f
+    local[k]["det"][0]["conf"] = f / 7.0
+    local[k]["hm_idx"][:] = f
+allr = shard.gather_records(local, n_frames, rank, world, transport="dist")
+assert len(allr) == n_frames, len(allr)
+assert allr["n_det"].tolist() == list(range(n_frames))
+assert allr["n_kp"].tolist() == [1000 + f for f in range(n_frames)]
+assert all(np.array_equal(allr[f]["H"], np.arange(9) + f) for f in range(n_frames))
+assert np.allclose(allr["det"]["conf"][:, 0], np.arange(n_frames) / 7.0)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", lo, hi)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, n_frames, tmp_path):
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(w), ROOT, str(n_frames)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+def test_two_rank_gather_even(tmp_path):
+    _run(2, 10, tmp_path)
+
+
+def test_two_rank_gather_ragged(tmp_path):
+    _run(2, 7, tmp_path)            # chunks of 4 and 3: the padded slot must be dropped
+
+
+def test_shard_ranges_cover_clip():
+    from eagle_amd import shard
+    for n in (0, 1, 7, 8, 1000, 8001):
+        for w in (1, 2, 3, 8):
+            r = [shard.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert all(hi - lo <= shard.chunk_size(n, w) for lo, hi in r)
+
+
+def test_world_one_gather_is_identity():
+    from eagle_amd import shard
+    from eagle_amd.lib import RESULT_DTYPE
+    a = np.zeros(3, RESULT_DTYPE)
+    a["n_det"] = [1, 2, 3]
+    assert shard.gather_records(a, 3, 0, 1)["n_det"].tolist() == [1, 2, 3]

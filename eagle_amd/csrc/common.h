@@ -60,6 +60,7 @@ struct ConvLaunch {
 bool conv_supported(int precision, const ConvConfig& cfg);
 void conv_launch(int precision, const ConvLaunch& L, hipStream_t s);
 size_t conv_weight_elems(int precision, const ConvConfig& cfg);
+size_t conv_lds_bytes(int precision, const ConvConfig& cfg);
 // w_hwio: folded fp32 weights [ks][ks][cin_real][cout_real]; dst: host buffer of conv_weight_elems elements
 void conv_tile_weights(int precision, const ConvConfig& cfg, const float* w_hwio, int cin_real, int cout_real, void* dst);
 ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo);

@@ -168,6 +168,9 @@ struct Builder {
                     hwio[((size_t)t * cin + i) * cout + o] = bn.empty() ? wv : (float)((double)wv * scale[o]);
                 }
         const int ho = (x.h + 2 * (ks / 2) - ks) / stride + 1, wo = (x.w + 2 * (ks / 2) - ks) / stride + 1;
+        if (const char* dump = getenv("EAGLE_DUMP_LAYERS")) {
+            if (FILE* f = fopen(dump, "a")) { fprintf(f, "%d,%d,%d,%d,%d,%d,%d\n", ks, stride, x.c, cout_pad, x.h, x.w, N); fclose(f); }
+        }
         ConvLaunch L;
         L.cfg = conv_choose(prec, ks, stride, x.c, cout_pad, wo);
         if (!conv_supported(prec, L.cfg))

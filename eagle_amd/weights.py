@@ -237,6 +237,8 @@ def make_hrnet_state_dict(seed=0):
 # Class-head biases [level][class] chosen offline by tests/golden/calibrate_cls_bias.py so that a synthetic
 # frame gives a few dozen candidates above the 0.15 floor; other (variant, seed) pairs use cls_bias.
 CLS_BIAS_TABLE = {
+    ("l", 0): [[-3.4716, -5.0677, 0.4193, -6.7448, -8.7873], [-5.1917, -12.6597, -3.9858, -7.1897, -18.0931],
+                 [3.3884, -5.8962, -23.0372, -7.8795, -2.8017]],   # calibrated at imgsz 960 (detector_large_hd)
     ("n", 0): [[-0.9421, -8.6099, 1.4466, -3.2987, -5.3539], [-7.2405, -8.2726, -12.5152, -11.3682, -2.6111], [-3.4973, -3.9737, -8.9049, -5.5132, -5.9112]],
 }
 

@@ -93,3 +93,44 @@ def test_batch_invariance(state_dicts, frames):
     rb2 = b.process_records(frames[::-1])[::-1]          # graph replay
     b.handle.close()
     assert ra.tobytes() == rb.tobytes() == rb2.tobytes()
+
+
+def test_rccl_gather_single_rank(state_dicts):
+    """eagle_comm_id / eagle_comm_init / eagle_gather through the real RCCL library (world size 1 on this box)."""
+    from eagle_amd import lib
+    h = lib.Handle(batch=1)
+    uid = lib.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    h.comm_init(0, 1, uid)
+    rec = np.zeros(5, lib.RESULT_DTYPE)
+    rec["n_det"] = np.arange(5)
+    rec["H"][:, 3] = 2.5
+    out = h.gather(rec, 1)
+    assert out.tobytes() == rec.tobytes()
+    h.close()
+
+
+def test_cfg3_large_detector_1080p_identical_to_oracle():
+    """BASELINE.json configs[2]: 1920x1080 frames, YOLOv8-l at imgsz 960 (544x960 letterbox) + HRNet-W48.
+    fp32 handle vs the exact-order oracle on one frame; algorithmic FLOP/frame must be 544.3 G."""
+    from eagle_amd import records, synth, weights
+    from eagle_amd.coordinate_model import CoordinateModel
+    from oracle import pipeline
+    hs, yl = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("l", 0)
+    frame = synth.frame(0, 3, 1080, 1920)
+    cm = CoordinateModel(precision="f32", batch=1, frame_hw=(1080, 1920), detector="l", det_imgsz=960,
+                         hrnet_state_dict=hs, detector_state_dict=yl)
+    rec = cm.process_records(frame[None])[0]
+    cm.handle.set_profiling(1)
+    cm.process_records(frame[None])
+    t = cm.handle.timings()
+    assert abs(t.conv_flop / 1e9 - 544.3) < 0.2, t.conv_flop
+    cm.handle.close()
+    ora = pipeline.OracleModel(hs, yl, variant="l", imgsz=960, backend="c")
+    oref, aux = ora.step(frame, 0)
+    assert np.array_equal(rec["hm_idx"], aux["hm_idx"])
+    n = int(rec["n_det"])
+    assert n == len(aux["dets"])
+    assert np.array_equal(np.stack([rec["det"][k][:n] for k in ("x1", "y1", "x2", "y2", "conf")], 1), aux["dets"][:, :5])
+    assert np.array_equal(rec["det"]["cls"][:n], aux["dets"][:, 5].astype(np.int32))
+    assert _canon(records.to_reference_dict(rec, 0)) == _canon(oref)

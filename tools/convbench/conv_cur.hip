@@ -15,8 +15,8 @@
 // Epilogue: v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); store (fp16 RNE / fp32).
 #include <algorithm>
 
-#include "common.h"
-#include "dmath.h"
+#include "../../eagle_amd/csrc/common.h"
+#include "../../eagle_amd/csrc/dmath.h"
 
 namespace eagle {
 
@@ -342,7 +342,7 @@ bool conv_supported(int precision, const ConvConfig& c) { return find_inst(preci
 
 struct Tuned { int ks, s, cin, cout, wo, kc, nt, wx; };
 static const Tuned g_tuned[] = {
-#include "conv_tuned.inc"
+#include "../../eagle_amd/csrc/conv_tuned.inc"
     {0, 0, 0, 0, 0, 0, 0, 0}};
 
 ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo)

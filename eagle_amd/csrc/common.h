@@ -46,6 +46,7 @@ struct ConvConfig {          // tile configuration chosen per layer at graph-bui
     int nt = 0;              // 16-wide Cout tiles per workgroup (BN = 16*nt)
     int wx = 2;              // 16-pixel sub-tiles per tile row; tile = (16/wx) rows x (16*wx) cols, 4 per wave
     int cin = 0, cout_pad = 0;
+    int variant = 0;         // fp16 only: 0 = register-staged, 1 = persistent LDS-DMA pipeline
 };
 struct ConvLaunch {
     ConvConfig cfg;

@@ -14,6 +14,7 @@
 //     accumulates these as a k-ordered fmaf chain, so outputs are bit-identical to oracle/eo_prims.c.
 // Epilogue: v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); store (fp16 RNE / fp32).
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../eagle_amd/csrc/common.h"
 #include "../../eagle_amd/csrc/dmath.h"
@@ -32,6 +33,7 @@ struct ConvArgs {
     const void* r2; int r2cs, r2off;
     int pre_act, post_act, out_f32;
     int wx, tiles_x, tiles_y, nchunks;
+    const void* zeros;      // >= 16 zero bytes in global memory (source of the halo's out-of-image pixels for LDS-DMA)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -189,6 +191,172 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// fp16 family, variant 1: persistent workgroups + double-buffered LDS filled by LDS-DMA (global_load_lds_dwordx4).
+//   * items = (tile, Cin-chunk) pairs; while the MFMAs of item i read LDS stage i&1, the DMA of item i+1 fills the other
+//     stage: no staging registers, no ds_write, one barrier per item.
+//   * LDS activation image is GROUP-MAJOR: [8-channel group][halo pixel][16 B].  A wave's DMA slab is 64 consecutive halo
+//     pixels of one group (lane-linear, as the DMA requires); a B-fragment read is 16 consecutive pixels = 256 contiguous
+//     bytes per lane quad, and quads of different groups sit a multiple of 1 KiB apart -> conflict-free ds_read_b128.
+//   * out-of-image halo pixels are DMA'd from a 16-byte zero page.
+// ------------------------------------------------------------------------------------------------------------
+template <int KS, int S, int KC, int NT>
+__global__ __launch_bounds__(256) void conv_f16_dma_kernel(ConvArgs a)
+{
+    constexpr int G = KC / 8;
+    constexpr int TAPS = KS * KS;
+    constexpr int NGR = TAPS * G;
+    constexpr int NI = (NGR + 3) / 4;
+    constexpr int BN = NT * 16;
+    constexpr int WBYTES = NI * 4 * BN * 16;
+    constexpr int WSLABS = WBYTES / 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int WX = a.wx, TH = 16 / WX, TW = 16 * WX;
+    const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
+    const int npix = halo_h * halo_w, npixp = (npix + 63) & ~63, pslabs = npixp >> 6;
+    const int act_bytes = G * npixp * 16;
+    const int stage_bytes = WBYTES + act_bytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, lx = lane & 15;
+    const int nb = blockIdx.y;
+    const int ntiles = a.tiles_x * a.tiles_y * a.N;
+    const _Float16* xg = (const _Float16*)a.x;
+    const _Float16* zp = (const _Float16*)a.zeros;
+
+    int abase[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+        abase[p] = ((row * S) * halo_w + (xb * 16 + lx) * S) * 16;
+    }
+    int koff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int g = 4 * i + q;
+        if (g < NGR) {
+            const int tap = g / G, cg = g - tap * G, ky = tap / KS, kx = tap - ky * KS;
+            koff[i] = (cg * npixp + ky * halo_w + kx) * 16;
+        } else {
+            koff[i] = 0;
+        }
+    }
+    const int wlane = (q * BN + lx) * 16;
+
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int t = blockIdx.x, ch = 0, stage = 0;
+    if (t >= ntiles) return;
+    int wleft = a.nchunks > 1 ? (1 << 30) : 2;     // single-chunk layers: fill the weight area of both stages once
+
+#define DMA_TILE_ORIGIN(T_, n_, oy0_, ox0_)                  \
+    int n_, oy0_, ox0_;                                      \
+    {                                                        \
+        int tt_ = (T_);                                      \
+        const int tx_ = tt_ % a.tiles_x; tt_ /= a.tiles_x;   \
+        const int ty_ = tt_ % a.tiles_y;                     \
+        n_ = tt_ / a.tiles_y; oy0_ = ty_ * TH; ox0_ = tx_ * TW; \
+    }
+#define DMA_ISSUE(T_, CH_, ST_, WL_)                                                                           \
+    {                                                                                                          \
+        char* sb_ = smem + (ST_) * stage_bytes;                                                                \
+        if (WL_) {                                                                                             \
+            const char* wsrc = (const char*)a.w + (size_t)(nb * a.nchunks + (CH_)) * WBYTES + lane * 16;       \
+            for (int ws = wave; ws < WSLABS; ws += 4)                                                          \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ws * 1024), \
+                                                 (__attribute__((address_space(3))) void*)(sb_ + ws * 1024), 16, 0, 0); \
+        }                                                                                                      \
+        DMA_TILE_ORIGIN(T_, n_i, oy0_i, ox0_i)                                                                 \
+        const int iy0 = oy0_i * S - KS / 2, ix0 = ox0_i * S - KS / 2;                                          \
+        const long long base = ((long long)(n_i * a.H + iy0) * a.W + ix0) * a.xcs + a.xoff + (CH_) * KC;       \
+        for (int ps = wave; ps < pslabs; ps += 4) {                                                            \
+            const int pix = ps * 64 + lane;                                                                    \
+            const int hy = pix / halo_w, hx = pix - hy * halo_w;                                               \
+            const int iy = iy0 + hy, ix = ix0 + hx;                                                            \
+            const bool ok = pix < npix && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                          \
+            const _Float16* src = ok ? xg + base + (long long)(hy * a.W + hx) * a.xcs : zp;                    \
+            _Pragma("unroll") for (int g = 0; g < G; ++g)                                                      \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (ok ? g * 8 : 0)), \
+                                                 (__attribute__((address_space(3))) void*)(sb_ + WBYTES + (g * npixp + ps * 64) * 16), 16, 0, 0); \
+        }                                                                                                      \
+    }
+
+    DMA_ISSUE(t, ch, 0, true)
+    --wleft;
+    for (;;) {
+        __syncthreads();                               // item i has landed (vmcnt(0)) and stage^1 is no longer being read
+        int nt_ = t, nch = ch + 1;
+        if (nch == a.nchunks) { nch = 0; nt_ = t + gridDim.x; }
+        const bool has_next = nt_ < ntiles;
+        if (has_next) {
+            const bool wl = wleft > 0;
+            DMA_ISSUE(nt_, nch, stage ^ 1, wl)
+            if (wl) --wleft;
+        }
+        const char* lds_w = smem + stage * stage_bytes;
+        const char* lds_a = lds_w + WBYTES;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            half8 wa[NT], xb[4];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) wa[tt] = *(const half8*)(lds_w + wlane + i * (4 * BN * 16) + tt * 256);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) xb[p] = *(const half8*)(lds_a + abase[p] + koff[i]);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
+        }
+        if (ch == a.nchunks - 1) {                     // epilogue: lane holds channels co..co+3 of pixel (oy, ox)
+            DMA_TILE_ORIGIN(t, n, oy0, ox0)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+                const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
+                const bool inb = oy < a.Ho && ox < a.Wo;
+                const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    if (inb) {
+                        const int co = nb * BN + tt * 16 + q * 4;
+                        const float4 bv = *(const float4*)(a.bias + co);
+                        float v[4] = {acc[tt][p][0] + bv.x, acc[tt][p][1] + bv.y, acc[tt][p][2] + bv.z, acc[tt][p][3] + bv.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.pre_act);
+                        if (a.r1) {
+                            const half4 rv = *(const half4*)((const _Float16*)a.r1 + pidx * a.r1cs + a.r1off + co);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
+                        }
+                        if (a.r2) {
+                            const half4 rv = *(const half4*)((const _Float16*)a.r2 + pidx * a.r2cs + a.r2off + co);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = v[r] + (float)rv[r];
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.post_act);
+                        if (a.out_f32) {
+                            *(float4*)((float*)a.y + pidx * a.ycs + a.yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                            *(half4*)((_Float16*)a.y + pidx * a.ycs + a.yoff + co) = o;
+                        }
+                    }
+                    acc[tt][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (!has_next) break;
+        t = nt_; ch = nch; stage ^= 1;
+    }
+#undef DMA_ISSUE
+#undef DMA_TILE_ORIGIN
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // fp32 exact family.  KC = 16 (or 4 for the 3-channel stems); canonical K order.
 // ------------------------------------------------------------------------------------------------------------
 template <int KS, int S, int KC, int NT>
@@ -308,6 +476,10 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
     const int th = 16 / c.wx, tw = 16 * c.wx;
     const int hw = (tw - 1) * c.stride + c.ks, hh = (th - 1) * c.stride + c.ks;
     const int bn = c.nt * 16;
+    if (precision == EAGLE_PREC_F16 && c.variant == 1) {
+        const size_t npixp = ((size_t)hh * hw + 63) & ~(size_t)63;
+        return 2 * ((size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)(c.kc / 8) * npixp * 16);
+    }
     if (precision == EAGLE_PREC_F16) return (size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)hh * hw * f16_ps(c.kc);
     return (size_t)c.ks * c.ks * (c.kc / 4) * 4 * bn * 4 + (size_t)hh * hw * (c.kc + 1) * 4;
 }
@@ -315,10 +487,10 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
 size_t conv_lds_bytes(int precision, const ConvConfig& c) { return lds_bytes(precision, c); }
 
 typedef void (*ConvKernel)(ConvArgs);
-struct Inst { int prec, ks, s, kc, nt; ConvKernel fn; };
+struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 
-#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, conv_f16_kernel<KS, S, KC, NT>}
-#define I32(KS, S, KC, NT) {EAGLE_PREC_F32, KS, S, KC, NT, conv_f32_kernel<KS, S, KC, NT>}
+#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT>}, {EAGLE_PREC_F16, KS, S, KC, NT, 1, conv_f16_dma_kernel<KS, S, KC, NT>}
+#define I32(KS, S, KC, NT) {EAGLE_PREC_F32, KS, S, KC, NT, 0, conv_f32_kernel<KS, S, KC, NT>}
 #define ALLNT16(KS, S, KC) I16(KS, S, KC, 1), I16(KS, S, KC, 2), I16(KS, S, KC, 3), I16(KS, S, KC, 4), I16(KS, S, KC, 6)
 #define ALLNT32(KS, S, KC) I32(KS, S, KC, 1), I32(KS, S, KC, 2), I32(KS, S, KC, 3), I32(KS, S, KC, 4), I32(KS, S, KC, 6)
 static const Inst g_inst[] = {
@@ -335,15 +507,15 @@ static const Inst g_inst[] = {
 static const Inst* find_inst(int precision, const ConvConfig& c)
 {
     for (const Inst& i : g_inst)
-        if (i.prec == precision && i.ks == c.ks && i.s == c.stride && i.kc == c.kc && i.nt == c.nt) return &i;
+        if (i.prec == precision && i.ks == c.ks && i.s == c.stride && i.kc == c.kc && i.nt == c.nt && i.variant == c.variant) return &i;
     return nullptr;
 }
 bool conv_supported(int precision, const ConvConfig& c) { return find_inst(precision, c) != nullptr; }
 
-struct Tuned { int ks, s, cin, cout, wo, kc, nt, wx; };
+struct Tuned { int ks, s, cin, cout, wo, kc, nt, wx, variant; };
 static const Tuned g_tuned[] = {
 #include "../../eagle_amd/csrc/conv_tuned.inc"
-    {0, 0, 0, 0, 0, 0, 0, 0}};
+    {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo)
 {
@@ -358,10 +530,17 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         c.kc = (cin_pad < 16) ? 4 : 16;
         return c;
     }
+    // developer override (parity tests of a specific kernel variant): EAGLE_CONV_FORCE="kc,nt,variant"
+    if (const char* f = getenv("EAGLE_CONV_FORCE")) {
+        ConvConfig q = c;
+        if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 &&
+            find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024)
+            return q;
+    }
     // fp16: per-layer table measured on MI355X (tools/autotune_conv.py); shapes not in the table use the heuristic below
     for (const Tuned& t : g_tuned)
         if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
-            ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx;
+            ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = t.variant;
             if (find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
         }
     // heuristic: the (NT, KC) pair with the most work per staged item whose LDS footprint still lets two workgroups share a CU
@@ -422,6 +601,15 @@ void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int c
     }
 }
 
+static const void* conv_zero_page()
+{
+    static void* z[64] = {};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (!z[dev]) { HIP_CHECK(hipMalloc(&z[dev], 256)); HIP_CHECK(hipMemset(z[dev], 0, 256)); }
+    return z[dev];
+}
+
 void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
 {
     const ConvConfig& c = L.cfg;
@@ -438,6 +626,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     const int th = 16 / c.wx, tw = 16 * c.wx;
     a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
     a.nchunks = c.cin / c.kc;
+    a.zeros = nullptr;
     const size_t lds = lds_bytes(precision, c);
     static bool attr_done[sizeof(g_inst) / sizeof(g_inst[0])] = {};
     const size_t ii = inst - g_inst;
@@ -445,7 +634,14 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         HIP_CHECK(hipFuncSetAttribute((const void*)inst->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[ii] = true;
     }
-    dim3 grid(a.tiles_x * a.tiles_y * a.N, c.cout_pad / (c.nt * 16));
+    const int gy = c.cout_pad / (c.nt * 16);
+    int gx = a.tiles_x * a.tiles_y * a.N;
+    if (c.variant == 1) {                                   // persistent: as many workgroups as stay resident
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+        gx = std::min(gx, std::max(1, (256 * per_cu + gy - 1) / gy));
+        a.zeros = conv_zero_page();
+    }
+    dim3 grid(gx, gy);
     hipLaunchKernelGGL(inst->fn, grid, dim3(256), lds, s, a);
     HIP_CHECK(hipGetLastError());
 }

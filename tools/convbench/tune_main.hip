@@ -1,5 +1,5 @@
 // Autotune driver: for every layer shape in argv[1] (lines "ks,s,cin,cout,h,w,n") time every supported fp16
-// (KC, NT, wx) configuration; prints "T,ks,s,cin,cout,h,w,n,kc,nt,wx,us".
+// (KC, NT, wx) configuration; prints "T,ks,s,cin,cout,h,w,n,kc,nt,wx,variant,us".
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -30,16 +30,17 @@ int main(int argc, char** argv)
     for (auto& sh : shapes) {
         std::tie(ks, s, cin, cout, h, w, n) = sh;
         const int ho = (h + 2 * (ks / 2) - ks) / s + 1, wo = (w + 2 * (ks / 2) - ks) / s + 1;
-        for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
+        for (int variant = 0; variant <= 1; ++variant) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
             if (cin % kc || cout % (16 * nt)) continue;
             ConvLaunch L;
-            L.cfg.ks = ks; L.cfg.stride = s; L.cfg.kc = kc; L.cfg.nt = nt; L.cfg.wx = wx; L.cfg.cin = cin; L.cfg.cout_pad = cout;
+            L.cfg.ks = ks; L.cfg.stride = s; L.cfg.kc = kc; L.cfg.nt = nt; L.cfg.wx = wx; L.cfg.cin = cin; L.cfg.cout_pad = cout; L.cfg.variant = variant;
             if (!conv_supported(EAGLE_PREC_F16, L.cfg)) continue;
             if (conv_lds_bytes(EAGLE_PREC_F16, L.cfg) > 160 * 1024 - 256) continue;
             if (conv_weight_elems(EAGLE_PREC_F16, L.cfg) * 2 > (64u << 20)) continue;
             L.x.p = dx; L.x.n = n; L.x.h = h; L.x.w = w; L.x.c = L.x.cs = cin;
             L.y.p = dy; L.y.n = n; L.y.h = ho; L.y.w = wo; L.y.c = L.y.cs = cout;
             L.w = dw; L.bias = (const float*)db; L.post_act = 1;
+            if (getenv("TUNE_VERBOSE")) { fprintf(stderr, "try ks=%d s=%d cin=%d cout=%d h=%d w=%d kc=%d nt=%d wx=%d var=%d lds=%zu\n", ks, s, cin, cout, h, w, kc, nt, wx, variant, conv_lds_bytes(EAGLE_PREC_F16, L.cfg)); fflush(stderr); }
             try {
                 conv_launch(EAGLE_PREC_F16, L, nullptr);
                 if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -48,7 +49,7 @@ int main(int argc, char** argv)
                 for (int i = 0; i < R; ++i) conv_launch(EAGLE_PREC_F16, L, nullptr);
                 hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
-                printf("T,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.2f\n", ks, s, cin, cout, h, w, n, kc, nt, wx, ms / R * 1e3);
+                printf("T,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.2f\n", ks, s, cin, cout, h, w, n, kc, nt, wx, variant, ms / R * 1e3);
             } catch (int) { (void)hipGetLastError(); }
         }
         fflush(stdout);

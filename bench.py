@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=20, help="distinct synthetic frames generated (tiled to the clip)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the network phase as a hipGraph (no gain once a step is GPU-bound)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
     a = ap.parse_args()
 
@@ -98,7 +98,7 @@ def main():
     ys = weights.make_yolo_state_dict(a.detector, 0)
     h = lib.Handle(device=local_rank, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
                    batch=B, precision=lib.PREC_F16 if a.precision == "f16" else lib.PREC_F32,
-                   use_graph=0 if a.no_graph else 1)
+                   use_graph=1 if a.graph else 0)
     weights.load_into(h, [hs, ys])
     log(f"rank {rank}: handle ready (batch {B})")
     gather_used = a.gather
@@ -159,6 +159,12 @@ def main():
     h.set_profiling(0)
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
 
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+    if os.path.exists(tf):
+        tj = json.load(open(tf))
+        if tj.get("batch") == B and tj.get("detector") == a.detector and tj.get("precision") == a.precision:
+            traffic = tj["conv_family"]["hbm_bytes_per_launch"]
     res = None
     if rank == 0:
         res = {
@@ -168,12 +174,14 @@ def main():
             "dtype": "f16" if a.precision == "f16" else "f32", "data": f"synthetic ({len(base)} distinct generated frames per rank tiled to {n_local}; seeded synthetic weights)",
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}",
-                       "gather": "none" if world == 1 else gather_used, "hip_graph": not a.no_graph},
-            "roofline": {"bound": "mfma", "kernel": "conv_f16_kernel<KS,S,KC,NT> (all convolution launches)" if a.precision == "f16" else "conv_f32_kernel",
+                       "gather": "none" if world == 1 else gather_used, "hip_graph": bool(a.graph)},
+            "roofline": {"bound": "mfma", "kernel": "conv_f16_kernel / conv_f16_dma_kernel <KS,S,KC,NT> (all 356 convolution launches of a step)" if a.precision == "f16" else "conv_f32_kernel",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3, "unit": "TFLOP/s",
                          "frac": round(achieved / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
                          "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
-                         "conv_ms_per_step": round(conv_ms / prof_steps, 3), "traffic": None},
+                         "conv_ms_per_step": round(conv_ms / prof_steps, 3),
+                         "algorithmic_bytes_note": "MFMA-bound kernel: achieved is FLOP-based; traffic = measured HBM bytes per conv launch (PMC)",
+                         "traffic": traffic},
         }
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())))

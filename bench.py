@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the network phase as a hipGraph (no gain once a step is GPU-bound)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --shared-gpu: dev test of the multi-rank path on one GPU)")
+    ap.add_argument("--shared-gpu", action="store_true", help="every rank uses HIP device 0 (developer test only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,16 +89,23 @@ def main():
 
     import torch
     dist = None
+    dev_index = 0 if a.shared_gpu else local_rank
+    tdev = "cuda" if a.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+            if a.gather == "rccl":
+                a.gather = "dist"
 
     from eagle_amd import lib, shard, synth, weights
     B, K, W = a.batch, a.steps, a.warmup
     hs = weights.make_hrnet_state_dict(0)
     ys = weights.make_yolo_state_dict(a.detector, 0)
-    h = lib.Handle(device=local_rank, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
+    h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
                    batch=B, precision=lib.PREC_F16 if a.precision == "f16" else lib.PREC_F32,
                    use_graph=1 if a.graph else 0)
     weights.load_into(h, [hs, ys])
@@ -108,7 +117,7 @@ def main():
         except Exception as e:                        # labelled, never silent: reported in the JSON line
             print(f"[bench] rank {rank}: library RCCL bootstrap failed ({e}); using torch.distributed all_gather", file=sys.stderr)
             gather_used = "dist"
-        flag = torch.tensor([1 if gather_used == "dist" else 0], device="cuda")
+        flag = torch.tensor([1 if gather_used == "dist" else 0], device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
             gather_used = "dist"
@@ -140,7 +149,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_frames = n_local * world

@@ -518,6 +518,7 @@ static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage sta
 {
     const int B = h->cfg.batch;
     memset(&h->timings, 0, sizeof(h->timings));
+    if (n == 0) return;
     HIP_CHECK(hipEventRecord(h->ev_t0, h->s_main));
     int prev_n = 0, prev_i = 0, k = 0;
     for (int i = 0; i < n; i += B, ++k) {
@@ -532,6 +533,7 @@ static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage sta
     hipStream_t sp = h->prof ? h->s_main : h->s_post;
     HIP_CHECK(hipEventRecord(h->ev_t1, sp));
     HIP_CHECK(hipEventSynchronize(h->ev_t1));
+    HIP_CHECK(hipEventSynchronize(h->ev_t0));
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     h->timings.total_ms = ms;

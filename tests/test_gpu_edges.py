@@ -1,0 +1,104 @@
+"""-m gpu: edge cases of the per-frame path (the reference has no tests; these are the cases its loop body guards with
+try/except or explicit checks: no detections, < 4 plane points -> no homography, empty input, ragged batches)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def records_equal(a, b):
+    """Field-wise equality (np.concatenate leaves struct padding bytes of structured arrays uninitialised)."""
+    def eq(x, y):
+        if x.dtype.names:
+            return all(eq(x[n], y[n]) for n in x.dtype.names)
+        return np.array_equal(x, y)
+    return a.shape == b.shape and eq(a, b)
+
+
+@pytest.fixture(scope="module")
+def model(state_dicts):
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    m = CoordinateModel(precision="f16", batch=4, hrnet_state_dict=hs, detector_state_dict=ys)
+    yield m
+    m.handle.close()
+
+
+def test_empty_clip_and_ragged_batches(model):
+    from eagle_amd import lib, synth
+    assert len(model.process_records(np.zeros((0, 720, 1280, 3), np.uint8))) == 0
+    frames = np.stack([synth.frame(2, t) for t in range(6)])       # 6 frames through batch 4: 4 + 2
+    a = model.process_records(frames)
+    b = np.concatenate([model.process_records(frames[i:i + 1]) for i in range(6)])
+    assert a.dtype == lib.RESULT_DTYPE and records_equal(a, b)
+
+
+def test_host_fed_equals_device_fed(model):
+    from eagle_amd import synth
+    frames = np.stack([synth.frame(5, t) for t in range(5)])
+    host = model.handle.process(frames)
+    d = model.handle.upload(frames)
+    dev = model.handle.process_device(d, len(frames))
+    model.handle.free(d)
+    assert records_equal(host, dev)
+
+
+def test_wrong_frame_shape_is_rejected(model):
+    from eagle_amd import lib
+    with pytest.raises(lib.EagleError):
+        model.process_records(np.zeros((1, 360, 640, 3), np.uint8))
+
+
+def test_blank_and_saturated_frames_give_consistent_records(model):
+    """Uniform frames: whatever the random-weight networks answer, the record must be internally consistent."""
+    frames = np.stack([np.zeros((720, 1280, 3), np.uint8), np.full((720, 1280, 3), 255, np.uint8)])
+    for rec in model.process_records(frames):
+        n, k = int(rec["n_det"]), int(rec["n_kp"])
+        assert 0 <= n <= 300 and 0 <= k <= 87 and n <= int(rec["n_candidates"])
+        d = rec["det"][:n]
+        assert np.all(np.diff(d["conf"]) <= 0)                                   # NMS order = descending confidence
+        assert np.all((d["x1"] >= 0) & (d["x2"] <= 1280) & (d["y1"] >= 0) & (d["y2"] <= 720))
+        persons = np.isin(d["cls"], (0, 1))
+        assert np.array_equal(d["id"][persons], np.nonzero(persons)[0])          # tracker-less IDs (cm.py:598-616)
+        balls = d["cls"] == 2
+        assert np.array_equal(d["id"][balls], np.arange(balls.sum()))            # enumerate index (cm.py:619-627)
+        assert np.all(d["id"][~persons & ~balls] == -1)
+        kp = rec["kp"][:k]
+        assert len(set(zip(kp["x"].tolist(), kp["y"].tolist()))) >= len(set(kp["label"].tolist())) - 30 or k == 0
+        assert len(set(kp["label"].tolist())) == k                               # one entry per landmark label
+        if not rec["H_valid"]:
+            assert not rec["bounds_valid"] and not d["in_bounds"].any()
+        else:
+            assert rec["H"][8] == 1.0 and kp["on_plane"].sum() >= 4 and kp["inlier"].sum() >= 4
+            inb = d["in_bounds"].astype(bool)
+            assert np.all((d["pitch_x"][inb] >= 0) & (d["pitch_x"][inb] <= 105) & (d["pitch_y"][inb] >= 0) & (d["pitch_y"][inb] <= 68))
+
+
+def test_high_keypoint_threshold_means_no_homography(state_dicts):
+    """keypoint_conf above every sigmoid maximum -> no keypoints -> H_valid = 0, every object keeps its image foot point
+    (the `H_use is None` branch, cm.py:379-380)."""
+    from eagle_amd import records, synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    m = CoordinateModel(keypoint_conf=1.5, precision="f16", batch=1, hrnet_state_dict=hs, detector_state_dict=ys)
+    rec = m.process_records(synth.frame(0, 1)[None])[0]
+    m.handle.close()
+    assert rec["n_kp"] == 0 and not rec["H_valid"]
+    ref = records.to_reference_dict(rec)
+    assert ref["Boundaries"] == [None] * 4 and ref["Keypoints"] == {}
+    for objs in ref["Coordinates"].values():
+        for o in objs.values():
+            assert o["Transformed_Coordinates"] is None and "Image_Bottom_center" in o
+
+
+def test_processor_process_api(state_dicts):
+    from eagle_amd import synth
+    from eagle_amd.processor import Processor
+    hs, ys = state_dicts
+    p = Processor(precision="f16", batch=1, hrnet_state_dict=hs, detector_state_dict=ys)
+    out = p.process(synth.frame(0, 9))
+    p.model.handle.close()
+    assert set(out) >= {"players", "ball", "H"}
+    assert out["H"] is None or out["H"].shape == (3, 3)
+    for pid, pl in out["players"].items():
+        assert isinstance(pid, int) and len(pl["BBox"]) == 4 and pl["Type"] in ("Player", "Goalkeeper")

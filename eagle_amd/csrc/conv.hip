@@ -33,6 +33,8 @@ struct ConvArgs {
     const void* r2; int r2cs, r2off;
     int pre_act, post_act, out_f32;
     int wx, tiles_x, tiles_y, nchunks;
+    int gy;                 // number of Cout blocks
+    int xcd;                // 1: XCD-aware work order (1-D grid; each XCD owns a contiguous range of (tile, Cout-block) items)
     const void* zeros;      // >= 16 zero bytes in global memory (source of the halo's out-of-image pixels for LDS-DMA)
 };
 
@@ -48,7 +50,7 @@ template <int KC> struct F16Geom {
 // (weight slice + halo tile) back to back into registers and only then writes them to LDS, so a chunk costs one memory
 // round trip instead of one per staging iteration; tile shapes are chosen so that two workgroups share a CU (LDS <= 80 KiB,
 // <= 256 VGPRs) and one workgroup's MFMAs hide the other's staging.
-template <int KS, int S, int KC, int NT>
+template <int KS, int S, int KC, int NT, bool PIPE, int PW>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
 {
     constexpr int G = F16Geom<KC>::G;
@@ -62,27 +64,35 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     char* lds_w = smem;
     char* lds_a = smem + WBYTES;
 
-    const int WX = a.wx, TH = 16 / WX, TW = 16 * WX;
+    const int WX = a.wx, TH = 4 * PW / WX, TW = 16 * WX;
     const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, lx = lane & 15;
-    int t = blockIdx.x;
+    int t = blockIdx.x, nb = blockIdx.y;
+    if (a.xcd) {
+        // The dispatcher places workgroup b on XCD b % 8 (observed; used for L2 locality only).  Give every XCD a contiguous
+        // range of items ordered (tile-major, Cout-block-minor): a tile's Cout-blocks re-read its halo from the same L2, and
+        // neighbouring tiles share their halo rows there.
+        const int gy = a.gy, total = a.tiles_x * a.tiles_y * a.N * gy;
+        const int b = blockIdx.x, xcd = b & 7, k = b >> 3, qn = total >> 3, rn = total & 7;
+        const int item = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + k;
+        t = item / gy; nb = item - t * gy;
+    }
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int n = t / a.tiles_y;
-    const int nb = blockIdx.y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - KS / 2, ix0 = ox0 * S - KS / 2;
 
-    f32x4 acc[NT][4];
+    f32x4 acc[NT][PW];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < PW; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int abase[4];
+    int abase[PW];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+    for (int p = 0; p < PW; ++p) {
+        const int s = wave * PW + p, row = s / WX, xb = s - row * WX;
         abase[p] = ((row * S) * halo_w + (xb * 16 + lx) * S) * PS;
     }
     int koff[NI];
@@ -100,64 +110,80 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     const _Float16* xg = (const _Float16*)a.x;
     const int ngroups = halo_h * halo_w * G;
 
+    // Staging of one Cin-chunk: every thread issues all of its 16-byte global loads back to back (LOAD), and writes them to
+    // LDS later (STORE).  PIPE = true: the loads of chunk ch+1 are issued before the MFMAs of chunk ch and land under them.
+    constexpr int MAXPIX = (KS == 1) ? 64 * PW : ((S == 1) ? (PW == 4 ? 340 : 204) : (PW == 4 ? 1105 : 585));   // largest halo over wx in {1,2}
+    constexpr int NPA = (MAXPIX * G + 255) / 256;
+    constexpr int NPW = (WBYTES / 16 + 255) / 256;
+    constexpr int RND = PIPE ? NPA : 8;                  // activation groups in flight per thread and round
+    static_assert(!PIPE || NPA <= 8, "pipelined staging is meant for small chunks");
+    uint4 pw[NPW], pa[RND];
+#define STAGE_LOAD(CH_, R0_)                                                                                            \
+    {                                                                                                                   \
+        const int c0_ = a.xoff + (CH_) * KC;                                                                            \
+        if ((R0_) == 0) {                                                                                               \
+            const char* wsrc_ = (const char*)a.w + (size_t)(nb * a.nchunks + (CH_)) * WBYTES;                           \
+            _Pragma("unroll") for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; pw[i] = *(const uint4*)(wsrc_ + (o < WBYTES ? o : 0)); } \
+        }                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < RND; ++j) {                                                               \
+            const int idx = tid + 256 * ((R0_) + j);                                                                    \
+            const int pix = idx / G, g = idx - pix * G;                                                                 \
+            const int hy = pix / halo_w, hx = pix - hy * halo_w;                                                        \
+            const int iy = iy0 + hy, ix = ix0 + hx;                                                                     \
+            uint4 v = make_uint4(0, 0, 0, 0);                                                                           \
+            if ((R0_) + j < NPA && idx < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)                         \
+                v = *(const uint4*)(xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0_ + g * 8);                    \
+            pa[j] = v;                                                                                                  \
+        }                                                                                                               \
+    }
+#define STAGE_STORE(R0_)                                                                                                \
+    {                                                                                                                   \
+        if ((R0_) == 0) {                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; if (o < WBYTES) *(uint4*)(lds_w + o) = pw[i]; } \
+        }                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < RND; ++j) {                                                               \
+            const int idx = tid + 256 * ((R0_) + j);                                                                    \
+            const int pix = idx / G, g = idx - pix * G;                                                                 \
+            if ((R0_) + j < NPA && idx < ngroups) *(uint4*)(lds_a + pix * PS + g * 16) = pa[j];                         \
+        }                                                                                                               \
+    }
+    if (PIPE) STAGE_LOAD(0, 0)
     for (int ch = 0; ch < a.nchunks; ++ch) {
-        {
-            constexpr int MAXPIX = (KS == 1) ? 256 : ((S == 1) ? 340 : 1105);
-            constexpr int NPA = (MAXPIX * G + 255) / 256;
-            constexpr int NPW = (WBYTES / 16 + 255) / 256;
-            constexpr int RND = 8;                      // activation groups in flight per thread and round
-            uint4 pw[NPW];
-            const char* wsrc = (const char*)a.w + (size_t)(nb * a.nchunks + ch) * WBYTES;
-            const int c0 = a.xoff + ch * KC;
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; pw[i] = *(const uint4*)(wsrc + (o < WBYTES ? o : 0)); }
+        if (PIPE) {
+            if (ch > 0) __syncthreads();                   // every wave is done reading the previous chunk from LDS
+            STAGE_STORE(0)
+            __syncthreads();
+            if (ch + 1 < a.nchunks) STAGE_LOAD(ch + 1, 0)
+        } else {
 #pragma unroll
             for (int r0 = 0; r0 < NPA; r0 += RND) {
-                uint4 pa[RND];
-#pragma unroll
-                for (int j = 0; j < RND; ++j) {
-                    const int idx = tid + 256 * (r0 + j);
-                    const int pix = idx / G, g = idx - pix * G;
-                    const int hy = pix / halo_w, hx = pix - hy * halo_w;
-                    const int iy = iy0 + hy, ix = ix0 + hx;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (r0 + j < NPA && idx < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                        v = *(const uint4*)(xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0 + g * 8);
-                    pa[j] = v;
-                }
-                if (r0 == 0) {
-#pragma unroll
-                    for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; if (o < WBYTES) *(uint4*)(lds_w + o) = pw[i]; }
-                }
-#pragma unroll
-                for (int j = 0; j < RND; ++j) {
-                    const int idx = tid + 256 * (r0 + j);
-                    const int pix = idx / G, g = idx - pix * G;
-                    if (r0 + j < NPA && idx < ngroups) *(uint4*)(lds_a + pix * PS + g * 16) = pa[j];
-                }
+                STAGE_LOAD(ch, r0)
+                STAGE_STORE(r0)
             }
+            __syncthreads();
         }
-        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            half8 wa[NT], xb[4];
+            half8 wa[NT], xb[PW];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) wa[tt] = *(const half8*)(lds_w + wlane + i * (4 * BN * 16) + tt * 256);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) xb[p] = *(const half8*)(lds_a + abase[p] + koff[i]);
+            for (int p = 0; p < PW; ++p) xb[p] = *(const half8*)(lds_a + abase[p] + koff[i]);
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < PW; ++p)
                     acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
         }
-        __syncthreads();
+        if (!PIPE) __syncthreads();
     }
+#undef STAGE_LOAD
+#undef STAGE_STORE
 
     // epilogue: lane holds channels co..co+3 of pixel (oy, ox)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+    for (int p = 0; p < PW; ++p) {
+        const int s = wave * PW + p, row = s / WX, xb = s - row * WX;
         const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
         if (oy >= a.Ho || ox >= a.Wo) continue;
         const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
@@ -471,9 +497,11 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgs a)
 static int f16_ps(int kc) { const int g = kc / 8; return kc * 2 + ((g % 2 == 0) ? 16 : 0); }
 static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
+static int conv_pw(const ConvConfig& c) { return c.variant == 3 ? 2 : 4; }
+
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
-    const int th = 16 / c.wx, tw = 16 * c.wx;
+    const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     const int hw = (tw - 1) * c.stride + c.ks, hh = (th - 1) * c.stride + c.ks;
     const int bn = c.nt * 16;
     if (precision == EAGLE_PREC_F16 && c.variant == 1) {
@@ -489,7 +517,11 @@ size_t conv_lds_bytes(int precision, const ConvConfig& c) { return lds_bytes(pre
 typedef void (*ConvKernel)(ConvArgs);
 struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 
-#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT>}, {EAGLE_PREC_F16, KS, S, KC, NT, 1, conv_f16_dma_kernel<KS, S, KC, NT>}
+#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}, {EAGLE_PREC_F16, KS, S, KC, NT, 1, conv_f16_dma_kernel<KS, S, KC, NT>}
+#define I16P(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 2, conv_f16_kernel<KS, S, KC, NT, true, 4>}
+#define I16H(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 3, conv_f16_kernel<KS, S, KC, NT, false, 2>}
+#define ALLNT16H(KS, S, KC) I16H(KS, S, KC, 1), I16H(KS, S, KC, 2), I16H(KS, S, KC, 3), I16H(KS, S, KC, 4), I16H(KS, S, KC, 6)
+#define ALLNT16P(KS, S, KC) I16P(KS, S, KC, 1), I16P(KS, S, KC, 2), I16P(KS, S, KC, 3), I16P(KS, S, KC, 4), I16P(KS, S, KC, 6)
 #define I32(KS, S, KC, NT) {EAGLE_PREC_F32, KS, S, KC, NT, 0, conv_f32_kernel<KS, S, KC, NT>}
 #define ALLNT16(KS, S, KC) I16(KS, S, KC, 1), I16(KS, S, KC, 2), I16(KS, S, KC, 3), I16(KS, S, KC, 4), I16(KS, S, KC, 6)
 #define ALLNT32(KS, S, KC) I32(KS, S, KC, 1), I32(KS, S, KC, 2), I32(KS, S, KC, 3), I32(KS, S, KC, 4), I32(KS, S, KC, 6)
@@ -500,6 +532,10 @@ static const Inst g_inst[] = {
     ALLNT16(3, 2, 8), ALLNT16(3, 2, 16), ALLNT16(3, 2, 32), ALLNT16(3, 2, 48),
     // 1x1
     ALLNT16(1, 1, 16), ALLNT16(1, 1, 32), ALLNT16(1, 1, 48), ALLNT16(1, 1, 64),
+    // chunk-pipelined staging (variant 2): small chunks only
+    ALLNT16P(3, 1, 16), ALLNT16P(3, 1, 32), ALLNT16P(1, 1, 16), ALLNT16P(1, 1, 32), ALLNT16P(1, 1, 48), ALLNT16P(1, 1, 64),
+    // half-size tiles (variant 3): 2 pixel sub-tiles per wave -> fewer registers / less LDS -> more resident workgroups
+    ALLNT16H(3, 1, 16), ALLNT16H(3, 1, 32), ALLNT16H(3, 1, 48), ALLNT16H(3, 2, 16), ALLNT16H(3, 2, 32), ALLNT16H(1, 1, 32), ALLNT16H(1, 1, 64),
     // exact fp32 family
     ALLNT32(3, 1, 16), ALLNT32(3, 2, 16), ALLNT32(3, 2, 4), ALLNT32(1, 1, 16),
 };
@@ -623,10 +659,10 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.r2 = L.r2.p; a.r2cs = L.r2.cs; a.r2off = L.r2.off;
     a.pre_act = L.pre_act; a.post_act = L.post_act; a.out_f32 = L.out_f32 || precision == EAGLE_PREC_F32;
     a.wx = c.wx;
-    const int th = 16 / c.wx, tw = 16 * c.wx;
+    const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
     a.nchunks = c.cin / c.kc;
-    a.zeros = nullptr;
+    a.zeros = nullptr; a.xcd = 0; a.gy = 1;
     const size_t lds = lds_bytes(precision, c);
     static bool attr_done[sizeof(g_inst) / sizeof(g_inst[0])] = {};
     const size_t ii = inst - g_inst;
@@ -641,7 +677,11 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         gx = std::min(gx, std::max(1, (256 * per_cu + gy - 1) / gy));
         a.zeros = conv_zero_page();
     }
+    a.gy = gy;
+    static const int xcd_env = getenv("EAGLE_CONV_XCD") ? atoi(getenv("EAGLE_CONV_XCD")) : 1;
+    a.xcd = (precision == EAGLE_PREC_F16 && c.variant != 1 && c.ks == 3 && xcd_env) ? 1 : 0;
     dim3 grid(gx, gy);
+    if (a.xcd) grid = dim3(gx * gy, 1);
     hipLaunchKernelGGL(inst->fn, grid, dim3(256), lds, s, a);
     HIP_CHECK(hipGetLastError());
 }

@@ -24,13 +24,20 @@ int main(int argc, char** argv)
     }
     void *dx, *dy, *dw, *db;
     hipMalloc(&dx, maxb); hipMalloc(&dy, maxb); hipMalloc(&dw, 64 << 20); hipMalloc(&db, 1 << 16);
-    hipMemset(dx, 0x11, maxb); hipMemset(dw, 0x11, 64 << 20); hipMemset(db, 0, 1 << 16);
+    {   // random operands (constant fills clock higher and mis-rank configurations)
+        std::vector<_Float16> hr(maxb / 2); unsigned st = 12345u;
+        for (auto& v : hr) { st = st * 1664525u + 1013904223u; v = (_Float16)(((int)(st >> 16) % 2001 - 1000) / 1000.0f); }
+        hipMemcpy(dx, hr.data(), maxb, hipMemcpyHostToDevice);
+        std::vector<_Float16> hw2((64 << 20) / 2);
+        for (auto& v : hw2) { st = st * 1664525u + 1013904223u; v = (_Float16)(((int)(st >> 16) % 2001 - 1000) / 20000.0f); }
+        hipMemcpy(dw, hw2.data(), 64 << 20, hipMemcpyHostToDevice);
+    } hipMemset(db, 0, 1 << 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     static const int kcs[] = {64, 48, 32, 16, 8}, nts[] = {6, 4, 3, 2, 1};
     for (auto& sh : shapes) {
         std::tie(ks, s, cin, cout, h, w, n) = sh;
         const int ho = (h + 2 * (ks / 2) - ks) / s + 1, wo = (w + 2 * (ks / 2) - ks) / s + 1;
-        for (int variant = 0; variant <= 1; ++variant) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
+        for (int variant = 0; variant <= 3; ++variant) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
             if (cin % kc || cout % (16 * nt)) continue;
             ConvLaunch L;
             L.cfg.ks = ks; L.cfg.stride = s; L.cfg.kc = kc; L.cfg.nt = nt; L.cfg.wx = wx; L.cfg.cin = cin; L.cfg.cout_pad = cout; L.cfg.variant = variant;

@@ -3,7 +3,7 @@
 
 One "step" = one pass of the hot path over one device batch of ``--batch`` synthetic frames that are already
 resident in HBM (C ABI: eagle_process_device_frames).  Default run = BASELINE.json configs[1]: a 1000-frame
-1280x720 synthetic clip, YOLOv8-n detector + HRNet-W48 keypoint model, one MI355X (40 steps x 25 frames).
+1280x720 synthetic clip, YOLOv8-n detector + HRNet-W48 keypoint model, one MI355X (20 steps x 50 frames).
 The K timed steps are issued as ONE library call over the K*batch-frame clip so that the library's two-deep pipeline
 (geometry + record copy of step i under the networks of step i+1) is part of what is measured.
 Multi-GPU (driver launches one rank per GPU through torch.distributed.run): frames shard by contiguous chunk,
@@ -64,9 +64,9 @@ def cpu_baseline(hs, ys, frames, n_frames, threads, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=25, help="frames per device step")
+    ap.add_argument("--batch", type=int, default=50, help="frames per device step")
     ap.add_argument("--detector", default="n")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--height", type=int, default=720)

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
 
     // Staging of one Cin-chunk: every thread issues all of its 16-byte global loads back to back (LOAD), and writes them to
     // LDS later (STORE).  PIPE = true: the loads of chunk ch+1 are issued before the MFMAs of chunk ch and land under them.
-    constexpr int MAXPIX = (KS == 1) ? 64 * PW : ((S == 1) ? (PW == 4 ? 340 : 204) : (PW == 4 ? 1105 : 585));   // largest halo over wx in {1,2}
+    constexpr int MAXPIX = (KS == 1) ? 64 * PW : ((S == 1) ? (PW == 4 ? 340 : (PW == 2 ? 204 : 136)) : (PW == 4 ? 1105 : (PW == 2 ? 585 : 325)));   // largest halo over wx in {1,2}
     constexpr int NPA = (MAXPIX * G + 255) / 256;
     constexpr int NPW = (WBYTES / 16 + 255) / 256;
     constexpr int RND = PIPE ? NPA : 8;                  // activation groups in flight per thread and round
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgs a)
 static int f16_ps(int kc) { const int g = kc / 8; return kc * 2 + ((g % 2 == 0) ? 16 : 0); }
 static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
-static int conv_pw(const ConvConfig& c) { return c.variant == 3 ? 2 : 4; }
+static int conv_pw(const ConvConfig& c) { return c.variant == 3 ? 2 : (c.variant == 4 ? 1 : 4); }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
@@ -521,6 +521,8 @@ struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 #define I16P(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 2, conv_f16_kernel<KS, S, KC, NT, true, 4>}
 #define I16H(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 3, conv_f16_kernel<KS, S, KC, NT, false, 2>}
 #define ALLNT16H(KS, S, KC) I16H(KS, S, KC, 1), I16H(KS, S, KC, 2), I16H(KS, S, KC, 3), I16H(KS, S, KC, 4), I16H(KS, S, KC, 6)
+#define I16Q(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 4, conv_f16_kernel<KS, S, KC, NT, false, 1>}
+#define ALLNT16Q(KS, S, KC) I16Q(KS, S, KC, 1), I16Q(KS, S, KC, 2), I16Q(KS, S, KC, 3), I16Q(KS, S, KC, 4), I16Q(KS, S, KC, 6)
 #define ALLNT16P(KS, S, KC) I16P(KS, S, KC, 1), I16P(KS, S, KC, 2), I16P(KS, S, KC, 3), I16P(KS, S, KC, 4), I16P(KS, S, KC, 6)
 #define I32(KS, S, KC, NT) {EAGLE_PREC_F32, KS, S, KC, NT, 0, conv_f32_kernel<KS, S, KC, NT>}
 #define ALLNT16(KS, S, KC) I16(KS, S, KC, 1), I16(KS, S, KC, 2), I16(KS, S, KC, 3), I16(KS, S, KC, 4), I16(KS, S, KC, 6)
@@ -535,7 +537,9 @@ static const Inst g_inst[] = {
     // chunk-pipelined staging (variant 2): small chunks only
     ALLNT16P(3, 1, 16), ALLNT16P(3, 1, 32), ALLNT16P(1, 1, 16), ALLNT16P(1, 1, 32), ALLNT16P(1, 1, 48), ALLNT16P(1, 1, 64),
     // half-size tiles (variant 3): 2 pixel sub-tiles per wave -> fewer registers / less LDS -> more resident workgroups
-    ALLNT16H(3, 1, 16), ALLNT16H(3, 1, 32), ALLNT16H(3, 1, 48), ALLNT16H(3, 2, 16), ALLNT16H(3, 2, 32), ALLNT16H(1, 1, 32), ALLNT16H(1, 1, 64),
+    ALLNT16H(3, 1, 16), ALLNT16H(3, 1, 32), ALLNT16H(3, 1, 48), ALLNT16H(3, 1, 64), ALLNT16H(3, 2, 8), ALLNT16H(3, 2, 16), ALLNT16H(3, 2, 32), ALLNT16H(1, 1, 16), ALLNT16H(1, 1, 32), ALLNT16H(1, 1, 48), ALLNT16H(1, 1, 64),
+    // quarter-size tiles (variant 4): 1 pixel sub-tile per wave
+    ALLNT16Q(3, 1, 16), ALLNT16Q(3, 1, 32), ALLNT16Q(3, 1, 48), ALLNT16Q(3, 1, 64), ALLNT16Q(3, 2, 16), ALLNT16Q(3, 2, 32), ALLNT16Q(1, 1, 32), ALLNT16Q(1, 1, 64),
     // exact fp32 family
     ALLNT32(3, 1, 16), ALLNT32(3, 2, 16), ALLNT32(3, 2, 4), ALLNT32(1, 1, 16),
 };

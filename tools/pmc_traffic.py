@@ -16,7 +16,7 @@ def load(d, counter):
     return per
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {"batch": 25, "detector": "n", "precision": "f16", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + " ".join(sys.argv[4:]),
+out = {"batch": 50, "detector": "n", "precision": "f16", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + " ".join(sys.argv[4:]),
        "corrections": "bytes = KiB*1024; FETCH_SIZE doubled (gfx950 under-report of wide coalesced reads)", "kernels": {}}
 tf = tw = n = 0
 for k in fetch:

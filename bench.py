@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the network phase as a hipGraph (no gain once a step is GPU-bound)")
+    ap.add_argument("--host-frames", action="store_true", help="also time the PCIe-inclusive path (frames in pageable host memory, eagle_process_frames); reported as pcie_inclusive, never as value")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --shared-gpu: dev test of the multi-rank path on one GPU)")
     ap.add_argument("--shared-gpu", action="store_true", help="every rank uses HIP device 0 (developer test only)")
@@ -156,6 +157,14 @@ def main():
     assert len(allrec) == total_frames
     log(f"timed region {dt:.3f} s -> {total_frames / dt:.1f} frames/s")
 
+    pcie = None
+    if a.host_frames:
+        h.process(clip[:2 * B])
+        t1 = time.perf_counter()
+        h.process(clip)
+        pcie = n_local / (time.perf_counter() - t1)
+        log(f"PCIe-inclusive (pageable host frames): {pcie:.1f} frames/s")
+
     # dominant kernel = the implicit-GEMM convolution family: per-launch HIP events on the launch stream
     h.set_profiling(1)
     prof_steps = 2
@@ -192,6 +201,8 @@ def main():
                          "algorithmic_bytes_note": "MFMA-bound kernel: achieved is FLOP-based; traffic = measured HBM bytes per conv launch (PMC)",
                          "traffic": traffic},
         }
+        if pcie is not None:
+            res["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s", "note": "frames in pageable host memory -> eagle_process_frames (H2D overlapped on a copy stream)"}
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())))
     h.free(d_clip)

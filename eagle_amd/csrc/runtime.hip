@@ -79,7 +79,7 @@ struct EagleHandle {
     std::map<std::string, HostTensor> weights;
     bool finalized = false;
     int prec = 0;
-    hipStream_t s_main = nullptr, s_det = nullptr, s_post = nullptr;
+    hipStream_t s_main = nullptr, s_det = nullptr, s_post = nullptr, s_copy = nullptr;
     hipEvent_t ev_pre = nullptr, ev_det = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     // two-deep software pipeline: geometry + record D2H of batch i overlap the networks of batch i+1
     struct StepBuf {
@@ -87,7 +87,7 @@ struct EagleHandle {
         EagleFrameResult* d_out = nullptr;
         EagleFrameResult* h_out = nullptr;   // pinned
         uint8_t* d_frames = nullptr;         // staging copy of the batch (stable pointer for the captured graph)
-        hipEvent_t ev_compute = nullptr, ev_done = nullptr;
+        hipEvent_t ev_compute = nullptr, ev_done = nullptr, ev_copy = nullptr;
         hipGraphExec_t gexec = nullptr;
         const uint8_t* g_src = nullptr; int g_n = 0;
     } sb[2];
@@ -563,6 +563,7 @@ static void finalize(EagleHandle* h)
         HIP_CHECK(hipHostMalloc((void**)&sb.h_out, sizeof(EagleFrameResult) * (size_t)B, hipHostMallocDefault));
         HIP_CHECK(hipEventCreateWithFlags(&sb.ev_compute, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&sb.ev_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sb.ev_copy, hipEventDisableTiming));
     }
     int A = 0;
     for (int l = 0; l < 3; ++l) A += h->levels[l].gh * h->levels[l].gw;
@@ -636,6 +637,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_main, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_det, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_post, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&nh->s_copy, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_pre, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_det, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&nh->ev_t0));
@@ -654,12 +656,14 @@ void eagle_destroy(EagleHandle* h)
         if (sb.h_out) (void)hipHostFree(sb.h_out);
         if (sb.ev_compute) (void)hipEventDestroy(sb.ev_compute);
         if (sb.ev_done) (void)hipEventDestroy(sb.ev_done);
+        if (sb.ev_copy) (void)hipEventDestroy(sb.ev_copy);
     }
     for (auto& e : h->conv_ev) (void)hipEventDestroy(e);
     h->hr.reset(); h->yo.reset(); h->misc.reset();
     if (h->s_main) (void)hipStreamDestroy(h->s_main);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
     if (h->s_post) (void)hipStreamDestroy(h->s_post);
+    if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
     for (hipEvent_t e : {h->ev_pre, h->ev_det, h->ev_t0, h->ev_t1}) if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -719,10 +723,17 @@ int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t fram
     const size_t fsz = (size_t)fh * fw * 3;
     if (row_stride == 0) row_stride = (int64_t)fw * 3;
     if (frame_stride == 0) frame_stride = row_stride * fh;
+    // H2D on its own stream: the upload of batch k+1 overlaps the networks of batch k.  (The staging buffer of parity p was
+    // last read by batch k-2, whose records the host has already collected.)
     run_pipeline(h, n, out, [&](int p, int i, int na) -> const uint8_t* {
+        hipStream_t sc = h->prof ? h->s_main : h->s_copy;
         for (int k = 0; k < na; ++k)
             HIP_CHECK(hipMemcpy2DAsync(h->sb[p].d_frames + (size_t)k * fsz, (size_t)fw * 3, bgr + (size_t)(i + k) * frame_stride,
-                                       (size_t)row_stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, h->s_main));
+                                       (size_t)row_stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, sc));
+        if (!h->prof) {
+            HIP_CHECK(hipEventRecord(h->sb[p].ev_copy, sc));
+            HIP_CHECK(hipStreamWaitEvent(h->s_main, h->sb[p].ev_copy, 0));
+        }
         return h->sb[p].d_frames;
     });
     API_END(h)

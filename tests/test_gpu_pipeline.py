@@ -158,7 +158,7 @@ def test_f16_path_vs_f16_emulating_oracle(state_dicts, frames):
     rows = nets.yolo_decode(nets.yolo_heads(ys, x, "n", backend="c", f16=True))
     dets = host.nms_and_scale(rows, 720, 1280, g["out_h"], g["out_w"])
     n = int(rec["n_det"])
-    assert abs(n - len(dets)) <= 3
+    assert abs(n - len(dets)) <= max(8, 0.05 * len(dets))      # candidates sitting on the 0.15 floor / 0.7 IoU may flip
     m = min(n, len(dets), 50)                                  # the confident head of the list must line up
     got = np.stack([rec["det"][k][:m] for k in ("x1", "y1", "x2", "y2")], 1)
     agree = (np.abs(got - dets[:m, :4]).max(1) < 1.0) & (rec["det"]["cls"][:m] == dets[:m, 5].astype(np.int32))

@@ -1,0 +1,51 @@
+"""Minimal command line for the plumbing configuration (BASELINE.json configs[0]): run a clip through
+the GPU path and write ``raw_coordinates.json`` exactly the way the reference's ``main.py:26-30`` does
+(``json.dump(coordinates, f, default=float)`` of ``CoordinateModel.get_coordinates``; schema ``docs/data.md:20-41``).
+
+    python -m eagle_amd.cli --frames 10 --fps 5 --out output/synthetic          # synthetic clip (no video decode here)
+    python -m eagle_amd.cli --clip frames.npy --fps 25 --out output/myclip       # uint8 [n,h,w,3] BGR frames
+
+Video decode/encode, the pandas post-processor and the annotated video of ``main.py:34-81`` are out of scope
+(SURVEY §8f rows 3-4).  The stateless cadence is used: key-points and homography on every frame."""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--clip", help=".npy file with uint8 [n,h,w,3] BGR frames (default: synthetic clip)")
+    ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--fps", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default="output/synthetic")
+    ap.add_argument("--detector", default="n")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--batch", type=int, default=10)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+
+    from . import synth
+    from .coordinate_model import CoordinateModel
+    frames = np.load(a.clip) if a.clip else synth.clip(a.seed, a.frames)
+    n, h, w, _ = frames.shape
+    model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
+                            precision=a.precision, device=a.device, seed=a.seed)
+    t0 = time.perf_counter()
+    coordinates = model.get_coordinates(frames, a.fps, num_homography=a.fps, num_keypoint_detection=a.fps, verbose=False)
+    dt = time.perf_counter() - t0
+    os.makedirs(a.out, exist_ok=True)
+    with open(os.path.join(a.out, "raw_coordinates.json"), "w") as f:
+        json.dump(coordinates, f, default=float)
+    with open(os.path.join(a.out, "metadata.json"), "w") as f:
+        json.dump({"fps": a.fps, "frames": n, "seconds": dt, "note": "team_mapping needs the post-processor (out of scope)"}, f)
+    print(f"{n} frames in {dt:.3f} s -> {os.path.join(a.out, 'raw_coordinates.json')}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

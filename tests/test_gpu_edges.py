@@ -102,3 +102,25 @@ def test_processor_process_api(state_dicts):
     assert out["H"] is None or out["H"].shape == (3, 3)
     for pid, pl in out["players"].items():
         assert isinstance(pid, int) and len(pl["BBox"]) == 4 and pl["Type"] in ("Player", "Goalkeeper")
+
+
+def test_cli_writes_reference_schema(tmp_path):
+    """configs[0]: 10-frame clip at --fps 5 -> raw_coordinates.json with the schema of docs/data.md:20-41."""
+    import json
+    from eagle_amd import cli
+    assert cli.main(["--frames", "10", "--fps", "5", "--out", str(tmp_path), "--batch", "4"]) == 0
+    d = json.load(open(tmp_path / "raw_coordinates.json"))
+    assert sorted(d, key=int) == [str(i) for i in range(10)]
+    for i, rec in d.items():
+        assert set(rec) == {"Coordinates", "Time", "Keypoints", "Boundaries"}
+        assert rec["Time"] == f"{int(i) // 5 // 60:02d}:{int(i) // 5 % 60:02d}"
+        assert len(rec["Boundaries"]) == 4
+        for cname, objs in rec["Coordinates"].items():
+            assert cname in ("Player", "Goalkeeper", "Ball")
+            for oid, o in objs.items():
+                int(oid)
+                assert len(o["BBox"]) == 4 and all(isinstance(v, int) for v in o["BBox"]) and 0 < o["Confidence"] <= 1
+                tc = o["Transformed_Coordinates"]
+                assert (tc is None and len(o["Image_Bottom_center"]) == 2) or (0 <= tc[0] <= 105 and 0 <= tc[1] <= 68)
+        for label, xy in rec["Keypoints"].items():
+            assert isinstance(label, str) and len(xy) == 2

@@ -36,11 +36,31 @@ class CoordinateModel:
                         verbose: bool = True, calibration: bool = False) -> dict:
         homography_interval = max(1, int(fps / max(1, num_homography)))
         keypoint_interval = max(1, int(fps / max(1, num_keypoint_detection)))
-        if calibration or homography_interval != 1 or keypoint_interval != 1:
-            raise NotImplementedError("only the stateless cadence (keypoint_interval == homography_interval == 1, "
-                                      "calibration off) is on the GPU path; see DESIGN.md 'out of scope'")
+        if calibration or keypoint_interval != 1:
+            raise NotImplementedError("key-points must be detected on every frame (keypoint_interval == 1, calibration off): "
+                                      "the LK-flow cadence is SURVEY §8f row 2; see DESIGN.md 'out of scope'")
         recs = self.process_records(frames)
-        return {i: records.to_reference_dict(r, i, fps) for i, r in enumerate(recs)}
+        own = np.ones(len(recs), bool)
+        if homography_interval > 1:
+            # cm.py:333-367: H is solved on scheduled frames or while the retry flag is set, and carried otherwise.  Every
+            # frame's own H is already in its record; decide in clip order whose H each frame uses, then let the GPU
+            # re-project the frames that use a carried one.
+            Hs = np.zeros((len(recs), 9)); flags = np.zeros(len(recs), np.uint8)
+            cur, retry = None, False
+            for i, r in enumerate(recs):
+                attempt = i % homography_interval == 0 or retry
+                if attempt and r["H_valid"]:
+                    cur, retry = r["H"].copy(), False
+                elif attempt:
+                    retry = True
+                own[i] = attempt and bool(r["H_valid"])
+                if not own[i]:
+                    flags[i] = 1 if cur is not None else 2
+                    if cur is not None:
+                        Hs[i] = cur
+            if flags.any():
+                recs = self.handle.reproject(np.ascontiguousarray(recs), Hs, flags)
+        return {i: records.to_reference_dict(r, i, fps, own_h=bool(own[i])) for i, r in enumerate(recs)}
 
     def detect_objects(self, frame):
         rec = self.process_records(frame[None])[0]

@@ -100,6 +100,7 @@ struct PostParams {
 };
 void nms_launch(const DetScratch& sc, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s);
 void post_launch(const ArgmaxPart* parts, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s);
+void reproject_launch(EagleFrameResult* d_recs, const double* d_Hs, const unsigned char* d_flags, int n, int frame_h, int frame_w, hipStream_t s);
 void homography_only_launch(const float* d_img, const float* d_world, int npts, double thresh, int max_iters, int lm_iters,
                             double* d_H, uint8_t* d_mask, int* d_ok, hipStream_t s);
 

@@ -763,6 +763,58 @@ void post_launch(const ArgmaxPart* parts, int n, const PostParams& pp, EagleFram
     HIP_CHECK(hipGetLastError());
 }
 
+// Re-projection with a carried homography (reference cadence homography_interval > 1, cm.py:333-415: between scheduled
+// frames the last successful H is reused for the foot points and the boundaries).  flag 1: use Hs[i]; flag 2: no H yet.
+struct ReprojArgs { EagleFrameResult* recs; const double* Hs; const unsigned char* flags; int frame_h, frame_w; };
+__global__ __launch_bounds__(POST_T) void reproject_kernel(ReprojArgs a)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int flag = a.flags[f];
+    if (flag == 0) return;
+    EagleFrameResult* R = a.recs + f;
+    __shared__ double H[9];
+    const bool Hok = flag == 1;
+    if (tid < 9) { H[tid] = Hok ? a.Hs[(size_t)f * 9 + tid] : 0.0; R->H[tid] = H[tid]; }
+    __syncthreads();
+    if (tid == 0) {
+        R->H_valid = Hok;
+        bool bok = false;
+        double bx[4] = {0, 0, 0, 0};
+        if (Hok) {
+            float cx[4], cy[4];
+            persp(H, 0.f, 0.f, &cx[0], &cy[0]);
+            persp(H, (float)a.frame_w, 0.f, &cx[1], &cy[1]);
+            persp(H, 0.f, (float)a.frame_h, &cx[2], &cy[2]);
+            persp(H, (float)a.frame_w, (float)a.frame_h, &cx[3], &cy[3]);
+            const double tlx = (int)cx[0], tly = (int)cy[0], trx = (int)cx[1], try_ = (int)cy[1];
+            const double blx = (int)cx[2], bly = (int)cy[2], brx = (int)cx[3], bry = (int)cy[3];
+            double ntl, ntr, nbl, nbr;
+            bok = find_x_at_y(tlx, tly, blx, bly, 68.0, &ntl) && find_x_at_y(trx, try_, brx, bry, 68.0, &ntr) &&
+                  find_x_at_y(blx, bly, ntl, 68.0, 0.0, &nbl) && find_x_at_y(brx, bry, ntr, 68.0, 0.0, &nbr);
+            if (bok) { bx[0] = nbl; bx[1] = ntl; bx[2] = ntr; bx[3] = nbr; }
+        }
+        R->bounds_valid = bok;
+        for (int k = 0; k < 4; ++k) R->bounds[k] = bx[k];
+    }
+    const int nd = R->n_det;
+    for (int k = tid; k < nd; k += POST_T) {
+        EagleDet* d = &R->det[k];
+        float ox = 0.f, oy = 0.f; int tx = 0, ty = 0; unsigned char inb = 0;
+        if (Hok) {
+            persp(H, (float)d->foot_x, (float)d->foot_y, &ox, &oy);
+            tx = (int)ox; ty = (int)oy;
+            inb = !(tx < 0 || tx > 105 || ty < 0 || ty > 68);
+        }
+        d->pitch_xf = ox; d->pitch_yf = oy; d->pitch_x = tx; d->pitch_y = ty; d->in_bounds = inb;
+    }
+}
+void reproject_launch(EagleFrameResult* d_recs, const double* d_Hs, const unsigned char* d_flags, int n, int frame_h, int frame_w, hipStream_t s)
+{
+    ReprojArgs a{d_recs, d_Hs, d_flags, frame_h, frame_w};
+    hipLaunchKernelGGL(reproject_kernel, dim3(n), dim3(POST_T), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
 // operator-level entry for the parity tests: findHomography only
 struct HomoArgs { const float* img; const float* world; int n; double thresh; int max_iters, lm_iters; double* H; uint8_t* mask; int* ok; const unsigned* rng_raw; };
 __global__ __launch_bounds__(POST_T) void homography_kernel(HomoArgs a)

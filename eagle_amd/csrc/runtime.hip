@@ -739,6 +739,27 @@ int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t fram
     API_END(h)
 }
 
+int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double* Hs, const uint8_t* flags)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!recs || !Hs || !flags || n < 0) fail(EAGLE_E_INVALID, "bad argument");
+    if (n == 0) return EAGLE_OK;
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    EagleFrameResult* d_r = nullptr; double* d_H = nullptr; unsigned char* d_f = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d_r, sizeof(EagleFrameResult) * (size_t)n));
+    HIP_CHECK(hipMalloc((void**)&d_H, sizeof(double) * 9 * (size_t)n));
+    HIP_CHECK(hipMalloc((void**)&d_f, (size_t)n));
+    HIP_CHECK(hipMemcpyAsync(d_r, recs, sizeof(EagleFrameResult) * (size_t)n, hipMemcpyHostToDevice, h->s_main));
+    HIP_CHECK(hipMemcpyAsync(d_H, Hs, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, h->s_main));
+    HIP_CHECK(hipMemcpyAsync(d_f, flags, (size_t)n, hipMemcpyHostToDevice, h->s_main));
+    reproject_launch(d_r, d_H, d_f, n, h->cfg.frame_h, h->cfg.frame_w, h->s_main);
+    HIP_CHECK(hipMemcpyAsync(recs, d_r, sizeof(EagleFrameResult) * (size_t)n, hipMemcpyDeviceToHost, h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    (void)hipFree(d_r); (void)hipFree(d_H); (void)hipFree(d_f);
+    API_END(h)
+}
+
 int eagle_device_alloc(EagleHandle* h, int64_t bytes, void** dptr)
 {
     if (!h) return EAGLE_E_INVALID;

@@ -74,6 +74,7 @@ def load():
     L.eagle_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
     L.eagle_device_free.argtypes = [vp, vp]
     L.eagle_device_upload.argtypes = [vp, vp, vp, i64]
+    L.eagle_reproject.argtypes = [vp, vp, i32, dp, u8p]
     L.eagle_comm_id.argtypes = [vp]
     L.eagle_comm_init.argtypes = [vp, i32, i32, vp]
     L.eagle_gather.argtypes = [vp, vp, i32, vp]
@@ -89,7 +90,7 @@ def load():
 
 EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_destroy", "eagle_last_error", "eagle_load_weights",
            "eagle_finalize_weights", "eagle_process_frames", "eagle_process_device_frames", "eagle_device_alloc",
-           "eagle_device_free", "eagle_device_upload", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
+           "eagle_device_free", "eagle_device_upload", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography"]
 
@@ -178,6 +179,15 @@ class Handle:
             out = np.zeros(n, RESULT_DTYPE)
         self._check(self.L.eagle_process_device_frames(self._h, dptr, n, out.ctypes.data_as(C.c_void_p)), "process_device_frames")
         return out
+
+    def reproject(self, recs, Hs, flags):
+        """In place: re-project foot points / boundaries of the flagged records with the given homographies (cadence mode)."""
+        Hs = np.ascontiguousarray(Hs, np.float64).reshape(-1, 9)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        assert recs.flags.c_contiguous and len(Hs) == len(flags) == len(recs)
+        self._check(self.L.eagle_reproject(self._h, recs.ctypes.data_as(C.c_void_p), len(recs), Hs.ctypes.data_as(C.POINTER(C.c_double)),
+                                           flags.ctypes.data_as(C.POINTER(C.c_uint8))), "reproject")
+        return recs
 
     def set_profiling(self, on):
         self._check(self.L.eagle_set_profiling(self._h, int(on)), "set_profiling")

@@ -19,8 +19,9 @@ def _objects(rec):
     return out
 
 
-def to_reference_dict(rec, i=0, fps=25):
-    """One record -> {"Coordinates", "Time", "Keypoints", "Boundaries"} exactly as cm.py:415 builds it."""
+def to_reference_dict(rec, i=0, fps=25, own_h=True):
+    """One record -> {"Coordinates", "Time", "Keypoints", "Boundaries"} exactly as cm.py:415 builds it.
+    own_h=False: the frame uses a carried homography (cadence mode): key-points are not inlier-filtered (cm.py:330,415)."""
     H_valid = bool(rec["H_valid"])
     coords = {}
     for cname, objs in _objects(rec).items():
@@ -34,7 +35,7 @@ def to_reference_dict(rec, i=0, fps=25):
                 cur["Image_Bottom_center"] = [int(d["foot_x"]), int(d["foot_y"])]
             coords.setdefault(cname, {})[oid] = cur
     kps = rec["kp"][: int(rec["n_kp"])]
-    if H_valid:   # cm.py:359-362: inliers only, values come back from img_pts.tolist() as floats
+    if H_valid and own_h:   # cm.py:359-362: inliers only, values come back from img_pts.tolist() as floats
         keypoints = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: [float(k["x"]), float(k["y"])]
                      for k in kps if k["on_plane"] and k["inlier"]}
     else:

@@ -130,6 +130,11 @@ int eagle_device_alloc(EagleHandle* h, int64_t bytes, void** dptr);
 int eagle_device_free(EagleHandle* h, void* dptr);
 int eagle_device_upload(EagleHandle* h, void* dptr, const void* src, int64_t bytes);
 
+/* Reference cadence with homography_interval > 1 (main.py:27 at --fps 5; cm.py:333-415): the caller decides, frame by frame in
+ * clip order, which frame's homography each frame uses (scheduled / retry / carried) and hands the records back:
+ * flags[i] = 0 keep the record, 1 re-project foot points and boundaries with Hs[9*i..], 2 no homography available yet. */
+int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double* Hs, const uint8_t* flags);
+
 /* Frame-sharded multi-GPU: rank r owns a contiguous chunk; one RCCL all-gather of records.
  * eagle_comm_id fills a 128-byte ncclUniqueId on rank 0; the caller broadcasts it (any channel). */
 int eagle_comm_id(void* id128);

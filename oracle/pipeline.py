@@ -54,3 +54,32 @@ class OracleModel:
         aux = dict(hm_idx=idx, hm_score=score, logits=logits, kp_detected=kp_detected, kp_synth=kp_synth,
                    dets=dets, rows=rows, objects=objects, H=H)
         return rec, aux
+
+
+def loop_records(per_frame, fps, num_homography, frame_h, frame_w):
+    """The reference loop body over a clip (cm.py:277-415) for keypoint_interval == 1 and ANY homography_interval:
+    H is solved on scheduled frames (i % homography_interval == 0) or while the retry flag `compute_homography` is set
+    (cm.py:350-351, 365-367) and carried forward otherwise.  per_frame: list of (keypoints dict as detect_keypoints
+    returns it, objects dict as detect_objects returns it).  The LK-flow rescue of frames with < 4 key-points
+    (cm.py:287-311) is NOT restated."""
+    homography_interval = max(1, int(fps / max(1, num_homography)))
+    res, H, compute_homography = {}, None, False
+    for i, (kps, objects) in enumerate(per_frame):
+        kps = dict(kps)
+        if len(kps) >= 2:
+            kps = host.synthesize_keypoints(kps)
+        prev_keypoints = kps
+        if i % homography_interval == 0 or compute_homography:
+            img_pts, world_pts, used = host.select_plane_points(kps)
+            if len(img_pts) < 4:
+                compute_homography = True
+            else:
+                Hn, mask = P.find_homography_ransac(img_pts, world_pts, 5.0)
+                if Hn is not None:
+                    prev_keypoints = {k: v for k, v, m in zip(used, img_pts.tolist(), mask.flatten()) if m}
+                    H, compute_homography = Hn, False
+                else:
+                    compute_homography = True
+        res[i] = {"Coordinates": host.project_objects(objects, H), "Time": f"{i // fps // 60:02d}:{i // fps % 60:02d}",
+                  "Keypoints": prev_keypoints, "Boundaries": host.boundaries(H, frame_h, frame_w)}
+    return res

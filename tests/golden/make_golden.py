@@ -150,6 +150,7 @@ def dump_loop():
     sys.modules["eagle.utils.pitch"] = load_by_path("eagle.utils.pitch", f"{REF}/eagle/utils/pitch.py")
     sys.modules["eagle.models.keypoint_hrnet"] = load_by_path("eagle.models.keypoint_hrnet", f"{REF}/eagle/models/keypoint_hrnet.py")
     cm = load_by_path("eagle.models.coordinate_model", f"{REF}/eagle/models/coordinate_model.py")
+    sys.modules["eagle.models.coordinate_model"] = cm
     out = []
     for kp, dets in make_cases():
         m = object.__new__(cm.CoordinateModel)
@@ -176,7 +177,41 @@ def dump_loop():
     print("loop golden:", len(out), "cases;", [(len(c["record"]["Keypoints"]), c["record"]["Boundaries"][0] is not None) for c in out])
 
 
+def dump_cadence():
+    """The reference loop exactly as main.py:27 calls it at --fps 5: get_coordinates(frames, 5, num_homography=1,
+    num_keypoint_detection=3) -> keypoint_interval 1, homography_interval 5 (H carried between scheduled frames, retry flag
+    cm.py:350-367).  Frames carry their index in pixel [0,0,0] so the stubs can serve per-frame canned outputs."""
+    cm = sys.modules["eagle.models.coordinate_model"]
+    cases = make_cases()
+    order = [4, 0, 1, 2, 3, 5, 6, 7, 0, 1, 2, 3]          # frame 0 = the "< 4 plane points" case -> retry on frame 1
+    kps = [cases[k][0] for k in order]
+    dets = [cases[k][1] for k in order]
+    frames = []
+    for i in range(len(order)):
+        f = np.zeros((720, 1280, 3), np.uint8); f[0, 0, 0] = i
+        frames.append(f)
+    m = object.__new__(cm.CoordinateModel)
+    m.device = "cpu"
+    m.class_names = {0: "Player", 1: "Goalkeeper", 2: "Ball", 3: "Referee", 4: "Staff members"}
+    m.keypoint_conf, m.detector_conf = 0.3, 0.35
+    m.lk_params = {}
+    m.transforms = lambda image: {"image": torch.full((3, 4, 4), float(image[0, 0, 0]))}
+    km = types.SimpleNamespace()
+    km.unnormalized_model = [None, types.SimpleNamespace(weight=types.SimpleNamespace(data=torch.zeros(1)))]
+    km.get_keypoints = lambda x: [list(kps[int(x[b, 0, 0, 0])]) for b in range(x.shape[0])]
+    m.keypoint_model = km
+    m.detector_model = lambda frame, verbose=False, conf=0.15: [types.SimpleNamespace(boxes=_Boxes(dets[int(frame[0, 0, 0])]))]
+    m.tracker = types.SimpleNamespace(update=lambda d, f: np.zeros((0, 8)))
+    res = m.get_coordinates(frames, 5, num_homography=1, num_keypoint_detection=3, verbose=False)
+    out = {"order": order, "fps": 5, "num_homography": 1, "num_keypoint_detection": 3,
+           "kp": [[list(t) for t in k] for k in kps], "dets": [d.tolist() for d in dets],
+           "records": json.loads(json.dumps(res, default=float))}
+    json.dump(out, open(f"{HERE}/cadence_golden.json", "w"))
+    print("cadence golden:", [(i, r["Boundaries"][0] is not None, len(r["Keypoints"])) for i, r in sorted(res.items())])
+
+
 if __name__ == "__main__":
     dump_pitch()
     dump_hrnet()
     dump_loop()
+    dump_cadence()

@@ -124,3 +124,35 @@ def test_cli_writes_reference_schema(tmp_path):
                 assert (tc is None and len(o["Image_Bottom_center"]) == 2) or (0 <= tc[0] <= 105 and 0 <= tc[1] <= 68)
         for label, xy in rec["Keypoints"].items():
             assert isinstance(label, str) and len(xy) == 2
+
+
+def test_reference_cadence_homography_every_5th_frame(state_dicts):
+    """main.py:27's exact call at --fps 5: get_coordinates(frames, 5, num_homography=1, num_keypoint_detection=3).
+    The GPU result must equal the oracle's restatement of the reference loop (pinned by cadence_golden.json) fed with
+    the same per-frame key-points / detections."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    from eagle_amd.pitch import INTERSECTION_TO_PITCH_POINTS
+    from oracle import host, pipeline
+    hs, ys = state_dicts
+    frames = np.stack([synth.frame(4, 3 * t) for t in range(7)])
+    m = CoordinateModel(precision="f16", batch=3, hrnet_state_dict=hs, detector_state_dict=ys)
+    got = m.get_coordinates(frames, 5, num_homography=1, num_keypoint_detection=3, verbose=False)
+    recs = m.process_records(frames)
+    m.handle.close()
+    per_frame = []
+    for r in recs:
+        kps = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"])) for k in r["kp"][: int(r["n_kp"])] if not k["synthesized"]}
+        n = int(r["n_det"])
+        dets = np.stack([r["det"][k][:n].astype(np.float32) for k in ("x1", "y1", "x2", "y2", "conf", "cls")], 1)
+        per_frame.append((kps, host.objects_from_detections(dets, 720, 1280)))
+    ref = pipeline.loop_records(per_frame, 5, 1, 720, 1280)
+
+    def canon(d):
+        if isinstance(d, dict):
+            return {str(k): canon(v) for k, v in d.items() if not str(k).startswith("_")}
+        if isinstance(d, (list, tuple)):
+            return [canon(v) for v in d]
+        return float(d) if isinstance(d, (np.floating, float)) else (int(d) if isinstance(d, np.integer) else d)
+    assert canon(got) == canon(ref)
+    assert len(got) == 7 and all(set(v) == {"Coordinates", "Time", "Keypoints", "Boundaries"} for v in got.values())

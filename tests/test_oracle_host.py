@@ -144,3 +144,17 @@ def test_boundaries_exceptions_become_none():
     assert host.boundaries(None, 720, 1280) == [None] * 4
     H = np.eye(3)                                       # corners map to themselves: left edge vertical -> ZeroDivisionError
     assert host.boundaries(H, 720, 1280) == [None] * 4
+
+
+def test_cadence_loop_matches_reference():
+    """main.py:27's exact call at --fps 5 (homography every 5th frame, carried in between, retry flag): the oracle's loop
+    against the records the reference's own get_coordinates produced (tests/golden/cadence_golden.json)."""
+    from oracle import host, pipeline
+    g = json.load(open(os.path.join(HERE, "golden", "cadence_golden.json")))
+    per_frame = []
+    for kp, dets in zip(g["kp"], g["dets"]):
+        decoded = [(int(i), x, y, s) for i, x, y, s in kp if s > 0.01]
+        per_frame.append((host.keypoints_from_decoded(decoded, 720, 1280),
+                          host.objects_from_detections(np.array(dets, np.float32).reshape(-1, 6), 720, 1280)))
+    res = pipeline.loop_records(per_frame, g["fps"], g["num_homography"], 720, 1280)
+    assert _canon(res) == g["records"]

@@ -517,7 +517,13 @@ size_t conv_lds_bytes(int precision, const ConvConfig& c) { return lds_bytes(pre
 typedef void (*ConvKernel)(ConvArgs);
 struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 
+// Variants 1 (LDS-DMA pipeline) and 2 (chunk-pipelined staging) lost to plain occupancy on every measured layer;
+// they are only instantiated for the autotuner (-DEAGLE_CONV_EXPERIMENTAL) to keep the library build short.
+#ifdef EAGLE_CONV_EXPERIMENTAL
 #define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}, {EAGLE_PREC_F16, KS, S, KC, NT, 1, conv_f16_dma_kernel<KS, S, KC, NT>}
+#else
+#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}
+#endif
 #define I16P(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 2, conv_f16_kernel<KS, S, KC, NT, true, 4>}
 #define I16H(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 3, conv_f16_kernel<KS, S, KC, NT, false, 2>}
 #define ALLNT16H(KS, S, KC) I16H(KS, S, KC, 1), I16H(KS, S, KC, 2), I16H(KS, S, KC, 3), I16H(KS, S, KC, 4), I16H(KS, S, KC, 6)
@@ -534,8 +540,10 @@ static const Inst g_inst[] = {
     ALLNT16(3, 2, 8), ALLNT16(3, 2, 16), ALLNT16(3, 2, 32), ALLNT16(3, 2, 48),
     // 1x1
     ALLNT16(1, 1, 16), ALLNT16(1, 1, 32), ALLNT16(1, 1, 48), ALLNT16(1, 1, 64),
+#ifdef EAGLE_CONV_EXPERIMENTAL
     // chunk-pipelined staging (variant 2): small chunks only
     ALLNT16P(3, 1, 16), ALLNT16P(3, 1, 32), ALLNT16P(1, 1, 16), ALLNT16P(1, 1, 32), ALLNT16P(1, 1, 48), ALLNT16P(1, 1, 64),
+#endif
     // half-size tiles (variant 3): 2 pixel sub-tiles per wave -> fewer registers / less LDS -> more resident workgroups
     ALLNT16H(3, 1, 16), ALLNT16H(3, 1, 32), ALLNT16H(3, 1, 48), ALLNT16H(3, 1, 64), ALLNT16H(3, 2, 8), ALLNT16H(3, 2, 16), ALLNT16H(3, 2, 32), ALLNT16H(1, 1, 16), ALLNT16H(1, 1, 32), ALLNT16H(1, 1, 48), ALLNT16H(1, 1, 64),
     // quarter-size tiles (variant 4): 1 pixel sub-tile per wave

@@ -159,7 +159,15 @@ def test_f16_path_vs_f16_emulating_oracle(state_dicts, frames):
     dets = host.nms_and_scale(rows, 720, 1280, g["out_h"], g["out_w"])
     n = int(rec["n_det"])
     assert abs(n - len(dets)) <= max(8, 0.05 * len(dets))      # candidates sitting on the 0.15 floor / 0.7 IoU may flip
-    m = min(n, len(dets), 50)                                  # the confident head of the list must line up
-    got = np.stack([rec["det"][k][:m] for k in ("x1", "y1", "x2", "y2")], 1)
-    agree = (np.abs(got - dets[:m, :4]).max(1) < 1.0) & (rec["det"]["cls"][:m] == dets[:m, 5].astype(np.int32))
-    assert agree.mean() > 0.9, f"top-{m} detections: {agree.mean():.2f} agree with the fp16-emulating oracle"
+    # order-insensitive: every confident oracle detection must have a GPU detection of the same class with IoU > 0.9
+    # (confidences that differ in the 4th digit permute the descending-confidence order)
+    g = np.stack([rec["det"][k][:n] for k in ("x1", "y1", "x2", "y2")], 1)
+    gcls = rec["det"]["cls"][:n]
+
+    def iou(a, b):
+        x1 = np.maximum(a[0], b[:, 0]); y1 = np.maximum(a[1], b[:, 1]); x2 = np.minimum(a[2], b[:, 2]); y2 = np.minimum(a[3], b[:, 3])
+        inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+        return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter + 1e-9)
+    conf = dets[dets[:, 4] >= 0.25]
+    hit = [bool(((iou(d[:4], g) > 0.9) & (gcls == int(d[5]))).any()) for d in conf]
+    assert len(conf) > 10 and np.mean(hit) > 0.95, f"{np.mean(hit):.2f} of {len(conf)} confident oracle detections found by the fp16 path"

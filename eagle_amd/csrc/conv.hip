@@ -220,15 +220,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
 // fp16 family, variant 1: persistent workgroups + double-buffered LDS filled by LDS-DMA (global_load_lds_dwordx4).
 //   * items = (tile, Cin-chunk) pairs; while the MFMAs of item i read LDS stage i&1, the DMA of item i+1 fills the other
 //     stage: no staging registers, no ds_write, one barrier per item.
-//   * LDS activation image is GROUP-MAJOR: [8-channel group][halo pixel][16 B].  A wave's DMA slab is 64 consecutive halo
-//     pixels of one group (lane-linear, as the DMA requires); a B-fragment read is 16 consecutive pixels = 256 contiguous
-//     bytes per lane quad, and quads of different groups sit a multiple of 1 KiB apart -> conflict-free ds_read_b128.
+//   * LDS activation image is pixel-major and UNPADDED ([halo pixel][KC] fp16): a DMA slab is 64 consecutive 16-byte groups in
+//     (pixel, group) order, so the global side reads runs of KC*2 contiguous bytes per pixel (as coalesced as the
+//     register-staged variant) while the LDS side is lane-linear as the DMA requires.
 //   * out-of-image halo pixels are DMA'd from a 16-byte zero page.
 // ------------------------------------------------------------------------------------------------------------
-template <int KS, int S, int KC, int NT>
+template <int KS, int S, int KC, int NT, int PW>
 __global__ __launch_bounds__(256) void conv_f16_dma_kernel(ConvArgs a)
 {
     constexpr int G = KC / 8;
+    constexpr int PS = KC * 2;
     constexpr int TAPS = KS * KS;
     constexpr int NGR = TAPS * G;
     constexpr int NI = (NGR + 3) / 4;
@@ -237,22 +238,22 @@ __global__ __launch_bounds__(256) void conv_f16_dma_kernel(ConvArgs a)
     constexpr int WSLABS = WBYTES / 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int WX = a.wx, TH = 16 / WX, TW = 16 * WX;
+    const int WX = a.wx, TH = 4 * PW / WX, TW = 16 * WX;
     const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
-    const int npix = halo_h * halo_w, npixp = (npix + 63) & ~63, pslabs = npixp >> 6;
-    const int act_bytes = G * npixp * 16;
-    const int stage_bytes = WBYTES + act_bytes;
+    const int ngroups = halo_h * halo_w * G;
+    const int aslabs = (ngroups + 63) >> 6;
+    const int stage_bytes = WBYTES + aslabs * 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, lx = lane & 15;
-    const int nb = blockIdx.y;
     const int ntiles = a.tiles_x * a.tiles_y * a.N;
+    const int gy = a.gy;
     const _Float16* xg = (const _Float16*)a.x;
     const _Float16* zp = (const _Float16*)a.zeros;
 
-    int abase[4];
+    int abase[PW];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
-        abase[p] = ((row * S) * halo_w + (xb * 16 + lx) * S) * 16;
+    for (int p = 0; p < PW; ++p) {
+        const int s = wave * PW + p, row = s / WX, xb = s - row * WX;
+        abase[p] = ((row * S) * halo_w + (xb * 16 + lx) * S) * PS;
     }
     int koff[NI];
 #pragma unroll
@@ -260,23 +261,37 @@ __global__ __launch_bounds__(256) void conv_f16_dma_kernel(ConvArgs a)
         const int g = 4 * i + q;
         if (g < NGR) {
             const int tap = g / G, cg = g - tap * G, ky = tap / KS, kx = tap - ky * KS;
-            koff[i] = (cg * npixp + ky * halo_w + kx) * 16;
+            koff[i] = (ky * halo_w + kx) * PS + cg * 16;
         } else {
             koff[i] = 0;
         }
     }
     const int wlane = (q * BN + lx) * 16;
 
-    f32x4 acc[NT][4];
+    f32x4 acc[NT][PW];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < PW; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int t = blockIdx.x, ch = 0, stage = 0;
-    if (t >= ntiles) return;
-    int wleft = a.nchunks > 1 ? (1 << 30) : 2;     // single-chunk layers: fill the weight area of both stages once
+    // work items of this workgroup: (tile, Cout block) pairs in XCD-contiguous order, each with nchunks chunks
+    const int nitems = ntiles * gy;
+    const int nwg = gridDim.x;
+    int item, item_end;
+    {   // the dispatcher places workgroup b on XCD b % 8: give every XCD a contiguous range of items (L2 locality only)
+        const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
+        const int per_xcd_wg = (nwg + 7 - xcd) >> 3;                       // workgroups on this XCD
+        const int qn = nitems >> 3, rn = nitems & 7;
+        const int x0 = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+        const int xc = qn + (xcd < rn ? 1 : 0);                            // items owned by this XCD
+        const int per = (xc + per_xcd_wg - 1) / per_xcd_wg;
+        item = x0 + k * per;
+        item_end = min(x0 + xc, item + per);
+    }
+    if (item >= item_end) return;
+    int ch = 0, stage = 0;
 
+#define DMA_ITEM(IT_, t_, nb_) const int t_ = (IT_) / gy, nb_ = (IT_) - t_ * gy;
 #define DMA_TILE_ORIGIN(T_, n_, oy0_, ox0_)                  \
     int n_, oy0_, ox0_;                                      \
     {                                                        \
@@ -285,62 +300,57 @@ __global__ __launch_bounds__(256) void conv_f16_dma_kernel(ConvArgs a)
         const int ty_ = tt_ % a.tiles_y;                     \
         n_ = tt_ / a.tiles_y; oy0_ = ty_ * TH; ox0_ = tx_ * TW; \
     }
-#define DMA_ISSUE(T_, CH_, ST_, WL_)                                                                           \
+#define DMA_ISSUE(IT_, CH_, ST_)                                                                               \
     {                                                                                                          \
         char* sb_ = smem + (ST_) * stage_bytes;                                                                \
-        if (WL_) {                                                                                             \
-            const char* wsrc = (const char*)a.w + (size_t)(nb * a.nchunks + (CH_)) * WBYTES + lane * 16;       \
-            for (int ws = wave; ws < WSLABS; ws += 4)                                                          \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ws * 1024), \
-                                                 (__attribute__((address_space(3))) void*)(sb_ + ws * 1024), 16, 0, 0); \
-        }                                                                                                      \
-        DMA_TILE_ORIGIN(T_, n_i, oy0_i, ox0_i)                                                                 \
+        DMA_ITEM(IT_, t_i, nb_i)                                                                               \
+        const char* wsrc = (const char*)a.w + (size_t)(nb_i * a.nchunks + (CH_)) * WBYTES + lane * 16;         \
+        for (int ws = wave; ws < WSLABS; ws += 4)                                                              \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ws * 1024), \
+                                             (__attribute__((address_space(3))) void*)(sb_ + ws * 1024), 16, 0, 0); \
+        DMA_TILE_ORIGIN(t_i, n_i, oy0_i, ox0_i)                                                                \
         const int iy0 = oy0_i * S - KS / 2, ix0 = ox0_i * S - KS / 2;                                          \
         const long long base = ((long long)(n_i * a.H + iy0) * a.W + ix0) * a.xcs + a.xoff + (CH_) * KC;       \
-        for (int ps = wave; ps < pslabs; ps += 4) {                                                            \
-            const int pix = ps * 64 + lane;                                                                    \
+        for (int as = wave; as < aslabs; as += 4) {                                                            \
+            const int e = as * 64 + lane;                                                                      \
+            const int pix = e / G, g = e - pix * G;                                                            \
             const int hy = pix / halo_w, hx = pix - hy * halo_w;                                               \
             const int iy = iy0 + hy, ix = ix0 + hx;                                                            \
-            const bool ok = pix < npix && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                          \
-            const _Float16* src = ok ? xg + base + (long long)(hy * a.W + hx) * a.xcs : zp;                    \
-            _Pragma("unroll") for (int g = 0; g < G; ++g)                                                      \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (ok ? g * 8 : 0)), \
-                                                 (__attribute__((address_space(3))) void*)(sb_ + WBYTES + (g * npixp + ps * 64) * 16), 16, 0, 0); \
+            const bool ok = e < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                         \
+            const _Float16* src = ok ? xg + base + (long long)(hy * a.W + hx) * a.xcs + g * 8 : zp;            \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,               \
+                                             (__attribute__((address_space(3))) void*)(sb_ + WBYTES + as * 1024), 16, 0, 0); \
         }                                                                                                      \
     }
 
-    DMA_ISSUE(t, ch, 0, true)
-    --wleft;
+    DMA_ISSUE(item, 0, 0)
     for (;;) {
         __syncthreads();                               // item i has landed (vmcnt(0)) and stage^1 is no longer being read
-        int nt_ = t, nch = ch + 1;
-        if (nch == a.nchunks) { nch = 0; nt_ = t + gridDim.x; }
-        const bool has_next = nt_ < ntiles;
-        if (has_next) {
-            const bool wl = wleft > 0;
-            DMA_ISSUE(nt_, nch, stage ^ 1, wl)
-            if (wl) --wleft;
-        }
+        int nit = item, nch = ch + 1;
+        if (nch == a.nchunks) { nch = 0; ++nit; }
+        const bool has_next = nit < item_end;
+        if (has_next) DMA_ISSUE(nit, nch, stage ^ 1)
         const char* lds_w = smem + stage * stage_bytes;
         const char* lds_a = lds_w + WBYTES;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            half8 wa[NT], xb[4];
+            half8 wa[NT], xb[PW];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) wa[tt] = *(const half8*)(lds_w + wlane + i * (4 * BN * 16) + tt * 256);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) xb[p] = *(const half8*)(lds_a + abase[p] + koff[i]);
+            for (int p = 0; p < PW; ++p) xb[p] = *(const half8*)(lds_a + abase[p] + koff[i]);
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < PW; ++p)
                     acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
         }
         if (ch == a.nchunks - 1) {                     // epilogue: lane holds channels co..co+3 of pixel (oy, ox)
+            DMA_ITEM(item, t, nb)
             DMA_TILE_ORIGIN(t, n, oy0, ox0)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int s = wave * 4 + p, row = s / WX, xb = s - row * WX;
+            for (int p = 0; p < PW; ++p) {
+                const int s = wave * PW + p, row = s / WX, xb = s - row * WX;
                 const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
                 const bool inb = oy < a.Ho && ox < a.Wo;
                 const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
@@ -376,10 +386,11 @@ __global__ __launch_bounds__(256) void conv_f16_dma_kernel(ConvArgs a)
             }
         }
         if (!has_next) break;
-        t = nt_; ch = nch; stage ^= 1;
+        item = nit; ch = nch; stage ^= 1;
     }
 #undef DMA_ISSUE
 #undef DMA_TILE_ORIGIN
+#undef DMA_ITEM
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -497,16 +508,16 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgs a)
 static int f16_ps(int kc) { const int g = kc / 8; return kc * 2 + ((g % 2 == 0) ? 16 : 0); }
 static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
-static int conv_pw(const ConvConfig& c) { return c.variant == 3 ? 2 : (c.variant == 4 ? 1 : 4); }
+static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 5) ? 2 : (c.variant == 4 ? 1 : 4); }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     const int hw = (tw - 1) * c.stride + c.ks, hh = (th - 1) * c.stride + c.ks;
     const int bn = c.nt * 16;
-    if (precision == EAGLE_PREC_F16 && c.variant == 1) {
-        const size_t npixp = ((size_t)hh * hw + 63) & ~(size_t)63;
-        return 2 * ((size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)(c.kc / 8) * npixp * 16);
+    if (precision == EAGLE_PREC_F16 && (c.variant == 1 || c.variant == 5)) {
+        const size_t aslabs = ((size_t)hh * hw * (c.kc / 8) + 63) / 64;
+        return 2 * ((size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + aslabs * 1024);
     }
     if (precision == EAGLE_PREC_F16) return (size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)hh * hw * f16_ps(c.kc);
     return (size_t)c.ks * c.ks * (c.kc / 4) * 4 * bn * 4 + (size_t)hh * hw * (c.kc + 1) * 4;
@@ -520,7 +531,7 @@ struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 // Variants 1 (LDS-DMA pipeline) and 2 (chunk-pipelined staging) lost to plain occupancy on every measured layer;
 // they are only instantiated for the autotuner (-DEAGLE_CONV_EXPERIMENTAL) to keep the library build short.
 #ifdef EAGLE_CONV_EXPERIMENTAL
-#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}, {EAGLE_PREC_F16, KS, S, KC, NT, 1, conv_f16_dma_kernel<KS, S, KC, NT>}
+#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}, {EAGLE_PREC_F16, KS, S, KC, NT, 1, conv_f16_dma_kernel<KS, S, KC, NT, 4>}, {EAGLE_PREC_F16, KS, S, KC, NT, 5, conv_f16_dma_kernel<KS, S, KC, NT, 2>}
 #else
 #define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}
 #endif
@@ -684,16 +695,18 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     }
     const int gy = c.cout_pad / (c.nt * 16);
     int gx = a.tiles_x * a.tiles_y * a.N;
-    if (c.variant == 1) {                                   // persistent: as many workgroups as stay resident
+    const bool dma = c.variant == 1 || c.variant == 5;
+    if (dma) {                                              // persistent: as many workgroups as stay resident, 1-D over items
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-        gx = std::min(gx, std::max(1, (256 * per_cu + gy - 1) / gy));
+        gx = std::min(gx * gy, 256 * per_cu);
         a.zeros = conv_zero_page();
     }
     a.gy = gy;
     static const int xcd_env = getenv("EAGLE_CONV_XCD") ? atoi(getenv("EAGLE_CONV_XCD")) : 1;
-    a.xcd = (precision == EAGLE_PREC_F16 && c.variant != 1 && c.ks == 3 && xcd_env) ? 1 : 0;
+    a.xcd = (precision == EAGLE_PREC_F16 && c.variant != 1 && c.variant != 5 && c.ks == 3 && xcd_env) ? 1 : 0;
     dim3 grid(gx, gy);
     if (a.xcd) grid = dim3(gx * gy, 1);
+    if (dma) grid = dim3(gx, 1);
     hipLaunchKernelGGL(inst->fn, grid, dim3(256), lds, s, a);
     HIP_CHECK(hipGetLastError());
 }

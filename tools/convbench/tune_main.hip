@@ -37,7 +37,7 @@ int main(int argc, char** argv)
     for (auto& sh : shapes) {
         std::tie(ks, s, cin, cout, h, w, n) = sh;
         const int ho = (h + 2 * (ks / 2) - ks) / s + 1, wo = (w + 2 * (ks / 2) - ks) / s + 1;
-        for (int variant = 0; variant <= 4; ++variant) if (variant != 1 && variant != 2) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
+        for (int variant = 0; variant <= 5; ++variant) if (variant != 2) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
             if (cin % kc || cout % (16 * nt)) continue;
             ConvLaunch L;
             L.cfg.ks = ks; L.cfg.stride = s; L.cfg.kc = kc; L.cfg.nt = nt; L.cfg.wx = wx; L.cfg.cin = cin; L.cfg.cout_pad = cout; L.cfg.variant = variant;

@@ -202,9 +202,11 @@ class Handle:
         buf = C.create_string_buffer(bytes(uid_bytes), 128)
         self._check(self.L.eagle_comm_init(self._h, rank, world, buf), "comm_init")
 
-    def gather(self, local, world):
+    def gather(self, local, world, out=None):
         local = np.ascontiguousarray(local)
-        out = np.zeros(len(local) * world, RESULT_DTYPE)
+        if out is None:
+            out = np.zeros(len(local) * world, RESULT_DTYPE)
+        assert out.dtype == RESULT_DTYPE and len(out) == len(local) * world and out.flags.c_contiguous
         self._check(self.L.eagle_gather(self._h, local.ctypes.data_as(C.c_void_p), len(local), out.ctypes.data_as(C.c_void_p)), "gather")
         return out
 

@@ -29,8 +29,9 @@ def _pad(local, c):
     return out
 
 
-def gather_records(local, n_frames, rank, world, handle=None, transport="rccl"):
-    """local: this rank's records (structured array).  Returns all ``n_frames`` records in frame order on every rank."""
+def gather_records(local, n_frames, rank, world, handle=None, transport="rccl", out=None):
+    """local: this rank's records (structured array).  Returns all ``n_frames`` records in frame order on every rank.
+    ``out``: optional preallocated (and pre-touched) [chunk_size*world] result buffer, used when no rank is ragged."""
     if world == 1:
         return np.ascontiguousarray(local)
     c = chunk_size(n_frames, world)
@@ -38,7 +39,7 @@ def gather_records(local, n_frames, rank, world, handle=None, transport="rccl"):
     if transport == "rccl":
         if handle is None:
             raise ValueError("transport='rccl' needs the library handle (eagle_comm_init must have been called)")
-        allr = handle.gather(padded, world)
+        allr = handle.gather(padded, world, out if (out is not None and len(out) == c * world) else None)
     elif transport == "dist":
         import torch
         import torch.distributed as dist
@@ -50,6 +51,8 @@ def gather_records(local, n_frames, rank, world, handle=None, transport="rccl"):
         allr = np.concatenate([o.cpu().numpy() for o in outs]).view(local.dtype)
     else:
         raise ValueError(transport)
+    if c * world == n_frames:          # no ragged rank: the gathered buffer already is the clip, in frame order
+        return allr
     keep = []
     for r in range(world):
         lo, hi = shard_range(n_frames, r, world)

@@ -34,31 +34,34 @@ struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
 // ------------------------------------------------------------------------------------------------------------
 struct Op {
-    enum Kind { CONV, OTHER } kind = OTHER;
+    enum Kind { CONV, OTHER, FORK, JOIN } kind = OTHER;
     std::function<void(hipStream_t)> run;
     double flop = 0;
     const char* tag = "";
+    int stream = 0;          // 0: the network's own stream; 1..3: HRNet branch streams (concurrent branches between fuses)
+    int nbranch = 0;         // FORK/JOIN: number of side streams involved
 };
 
 struct Net {                      // one launch schedule + the device memory it owns
     std::vector<Op> ops;
     std::vector<void*> owned;
-    std::multimap<size_t, void*> free_list;
+    std::multimap<size_t, void*> free_list[4];   // one pool per stream: a buffer is recycled only by work ordered after its last use
+    int pool = 0;                                // pool of the stream the builder is currently emitting for
     std::map<void*, size_t> sizes;
     size_t bytes = 0;
     ~Net() { for (void* p : owned) (void)hipFree(p); }
     void* get(size_t b)
     {
         b = (b + 255) & ~(size_t)255;
-        auto it = free_list.find(b);
-        if (it != free_list.end()) { void* p = it->second; free_list.erase(it); return p; }
+        auto it = free_list[pool].find(b);
+        if (it != free_list[pool].end()) { void* p = it->second; free_list[pool].erase(it); return p; }
         void* p = nullptr;
         HIP_CHECK(hipMalloc(&p, b));
         HIP_CHECK(hipMemset(p, 0, b));
         owned.push_back(p); sizes[p] = b; bytes += b;
         return p;
     }
-    void put(void* p) { if (p) free_list.insert({sizes.at(p), p}); }
+    void put(void* p) { if (p) free_list[pool].insert({sizes.at(p), p}); }
     void* upload(const void* src, size_t b)
     {
         void* p = nullptr;
@@ -80,6 +83,9 @@ struct EagleHandle {
     bool finalized = false;
     int prec = 0;
     hipStream_t s_main = nullptr, s_det = nullptr, s_post = nullptr, s_copy = nullptr;
+    hipStream_t s_br[3] = {nullptr, nullptr, nullptr};          // HRNet branches 1..3 (branch 0 stays on s_main)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    bool multi_stream = true;
     hipEvent_t ev_pre = nullptr, ev_det = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     // two-deep software pipeline: geometry + record D2H of batch i overlap the networks of batch i+1
     struct StepBuf {
@@ -120,6 +126,9 @@ struct Builder {
     int prec;
     double bn_eps;
     int N;
+    int cur_stream = 0;
+    void set_stream(int k) { cur_stream = k; net->pool = k; }
+    void fork_join(Op::Kind kind, int nbranch) { Op op; op.kind = kind; op.nbranch = nbranch; op.tag = kind == Op::FORK ? "fork" : "join"; net->ops.push_back(op); }
 
     int gran() const { return prec == EAGLE_PREC_F16 ? 8 : 4; }
 
@@ -192,14 +201,14 @@ struct Builder {
         L.pre_act = pre; L.post_act = post; L.out_f32 = out_f32 ? 1 : 0;
         L.flop = 2.0 * N * ho * wo * (double)cout * cin * ks * ks;
         const int pr = prec;
-        Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = "conv";
+        Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = "conv"; op.stream = cur_stream;
         op.run = [L, pr](hipStream_t s) { conv_launch(pr, L, s); };
         net->ops.push_back(op);
         return L.y;
     }
     void other(std::function<void(hipStream_t)> fn, const char* tag)
     {
-        Op op; op.kind = Op::OTHER; op.run = std::move(fn); op.tag = tag;
+        Op op; op.kind = Op::OTHER; op.run = std::move(fn); op.tag = tag; op.stream = cur_stream;
         net->ops.push_back(op);
     }
 };
@@ -215,7 +224,9 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
     const int R = ACT_RELU;
     for (int m = 0; m < n_modules; ++m) {
         const std::string q = std::string(HRP) + "stage" + std::to_string(stage_idx) + "." + std::to_string(m) + ".";
+        B.fork_join(Op::FORK, nb - 1);          // the branches of a module are independent until the fuse
         for (int b = 0; b < nb; ++b) {
+            B.set_stream(b);
             TView x = xs[b];
             for (int k = 0; k < 4; ++k) {
                 const std::string r = q + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
@@ -227,6 +238,8 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
             }
             xs[b] = x;
         }
+        B.set_stream(0);
+        B.fork_join(Op::JOIN, nb - 1);
         const int n_out = (last_single && m == n_modules - 1) ? 1 : nb;
         std::vector<TView> out;
         for (int i = 0; i < n_out; ++i) {
@@ -427,13 +440,30 @@ static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3
 // ------------------------------------------------------------------------------------------------------------
 static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
 {
+    const bool multi = h->multi_stream && !h->prof;
     for (Op& op : net->ops) {
+        if (op.kind == Op::FORK) {
+            if (multi) {
+                HIP_CHECK(hipEventRecord(h->ev_fork, s));
+                for (int k = 0; k < op.nbranch; ++k) HIP_CHECK(hipStreamWaitEvent(h->s_br[k], h->ev_fork, 0));
+            }
+            continue;
+        }
+        if (op.kind == Op::JOIN) {
+            if (multi)
+                for (int k = 0; k < op.nbranch; ++k) {
+                    HIP_CHECK(hipEventRecord(h->ev_join[k], h->s_br[k]));
+                    HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[k], 0));
+                }
+            continue;
+        }
+        hipStream_t st = (multi && op.stream > 0) ? h->s_br[op.stream - 1] : s;
         if (h->prof && op.kind == Op::CONV) {
-            HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], s));
-            op.run(s);
-            HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], s));
+            HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], st));
+            op.run(st);
+            HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], st));
         } else {
-            op.run(s);
+            op.run(st);
         }
     }
 }
@@ -638,6 +668,10 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_det, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_post, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_copy, hipStreamNonBlocking));
+    for (auto& st : nh->s_br) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&nh->ev_fork, hipEventDisableTiming));
+    for (auto& e : nh->ev_join) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    nh->multi_stream = !getenv("EAGLE_SINGLE_STREAM");
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_pre, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_det, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&nh->ev_t0));
@@ -664,6 +698,9 @@ void eagle_destroy(EagleHandle* h)
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
     if (h->s_post) (void)hipStreamDestroy(h->s_post);
     if (h->s_copy) (void)hipStreamDestroy(h->s_copy);
+    for (auto st : h->s_br) if (st) (void)hipStreamDestroy(st);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (auto e : h->ev_join) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {h->ev_pre, h->ev_det, h->ev_t0, h->ev_t1}) if (e) (void)hipEventDestroy(e);
     delete h;
 }

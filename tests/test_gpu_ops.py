@@ -55,6 +55,27 @@ def test_conv_parity(case, prec):
         assert err < F16_TOL, f"fp16 conv error {err}"
 
 
+@pytest.mark.parametrize("force,cin,cout", [("48,3,6", 48, 48), ("48,3,7", 48, 48), ("96,3,7", 96, 96), ("96,3,6", 96, 96),
+                                            ("64,4,7", 64, 64), ("96,2,7", 96, 32)])
+@pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16)])
+def test_conv_weight_stationary_variants(force, cin, cout, shape, monkeypatch):
+    """The persistent weight-stationary 3x3 kernels (conv.hip variants 6/7), forced through EAGLE_CONV_FORCE, against the
+    oracle on ragged maps (partial tiles, more workgroup slots than tiles, several tiles per workgroup)."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    monkeypatch.setenv("EAGLE_CONV_FORCE", force)
+    n, h, w = shape
+    x = _rand((n, h, w, cin), 11)
+    wt = _rand((3, 3, cin, cout), 12, (2.0 / (cin * 9)) ** 0.5)
+    b = _rand((cout,), 13, 0.1)
+    r1 = _rand((n, h, w, cout), 14)
+    q = P.round_f16
+    ref = P.conv2d(q(x), q(wt), b, stride=1, pre=0, r1=q(r1), r2=None, post=1, f16_out=True)
+    got = lib.op_conv2d(x, wt, b, 1, 0, r1, None, 1, lib.PREC_F16)
+    err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < F16_TOL, f"fp16 weight-stationary conv error {err}"
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16"])
 def test_fuse_sum_parity(prec):
     from eagle_amd import lib

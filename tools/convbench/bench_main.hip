@@ -21,6 +21,10 @@ int main(int argc, char** argv)
         L.cfg = conv_choose(EAGLE_PREC_F16, sh.ks, sh.s, sh.cin, sh.cout, wo);
         if (getenv("KC")) L.cfg.kc = atoi(getenv("KC"));
         if (getenv("NT")) L.cfg.nt = atoi(getenv("NT"));
+        if (getenv("VAR")) L.cfg.variant = atoi(getenv("VAR"));
+        if (getenv("WX")) L.cfg.wx = atoi(getenv("WX"));
+        if (getenv("KC") && atoi(getenv("KC")) == 0) L.cfg.kc = sh.cin;
+        if (getenv("ONLY") && atoi(getenv("ONLY")) != sh.cin) continue;
         if (!conv_supported(EAGLE_PREC_F16, L.cfg)) { printf("%s: unsupported kc=%d nt=%d\n", sh.name, L.cfg.kc, L.cfg.nt); continue; }
         size_t nx = (size_t)sh.n * sh.h * sh.w * sh.cin, ny = (size_t)sh.n * ho * wo * sh.cout;
         std::vector<_Float16> hx(nx);
@@ -48,7 +52,7 @@ int main(int argc, char** argv)
         const double fl = 2.0 * sh.n * ho * wo * (double)sh.cout * sh.cin * sh.ks * sh.ks;
         std::vector<_Float16> hy(ny); hipMemcpy(hy.data(), dy, ny * 2, hipMemcpyDeviceToHost);
         double cs = 0; for (size_t i = 0; i < ny; i += 97) cs += (float)hy[i];
-        printf("%-22s kc=%2d nt=%d  %8.1f us  %7.1f TFLOP/s  checksum %.3f\n", sh.name, L.cfg.kc, L.cfg.nt, ms / R * 1e3, fl / (ms / R * 1e-3) / 1e12, cs);
+        printf("%-22s kc=%2d nt=%d var=%d wx=%d  %8.1f us  %7.1f TFLOP/s  checksum %.3f\n", sh.name, L.cfg.kc, L.cfg.nt, L.cfg.variant, L.cfg.wx, ms / R * 1e3, fl / (ms / R * 1e-3) / 1e12, cs);
         hipFree(dx); hipFree(dy); hipFree(dw); hipFree(db);
     }
     return 0;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     constexpr int WBYTES = NI * 4 * BN * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lds_w = smem;
-    char* lds_a = smem + WBYTES;
+    char* lds_a = smem + WBYTES + 16;                      // 16 spare bytes below the halo image: target of the items beyond it
 
     const int WX = a.wx, TH = 4 * PW / WX, TW = 16 * WX;
     const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
@@ -209,45 +209,48 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
         }
     }
     const int wlane = (q * BN + lx) * 16;
-    const _Float16* xg = (const _Float16*)a.x;
     const int ngroups = halo_h * halo_w * G;
 
     // Staging of one Cin-chunk: every thread issues all of its 16-byte global loads back to back (LOAD), and writes them to
     // LDS later (STORE).  PIPE = true: the loads of chunk ch+1 are issued before the MFMAs of chunk ch and land under them.
+    // The geometry of a thread's items does not depend on the chunk: their global byte offsets (out-of-image -> beyond the buffer,
+    // which loads as zeros) and LDS offsets are computed once; a chunk adds only a scalar offset.
     constexpr int MAXPIX = (KS == 1) ? 64 * PW : ((S == 1) ? (PW == 4 ? 340 : (PW == 2 ? 204 : 136)) : (PW == 4 ? 1105 : (PW == 2 ? 585 : 325)));   // largest halo over wx in {1,2}
     constexpr int NPA = (MAXPIX * G + 255) / 256;
     constexpr int NPW = (WBYTES / 16 + 255) / 256;
     constexpr int RND = PIPE ? NPA : 8;                  // activation groups in flight per thread and round
     static_assert(!PIPE || NPA <= 8, "pipelined staging is meant for small chunks");
-    uint4 pw[NPW], pa[RND];
+    const rsrc_t xrs = tensor_rsrc(a.x), wrs = tensor_rsrc(a.w);
+    unsigned aoff[NPA];
+    int ldso[NPA];
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int idx = tid + 256 * j;
+        const int pix = idx / G, g = idx - pix * G;
+        const int hy = pix / halo_w, hx = pix - hy * halo_w;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = idx < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        aoff[j] = ok ? (unsigned)(((n * a.H + iy) * a.W + ix) * a.xcs + g * 8) * 2u : OOB_OFF;
+        ldso[j] = idx < ngroups ? pix * PS + g * 16 : -16;                 // -16: the spare slot below the halo image
+    }
+    u32x4 pw[NPW], pa[RND];
 #define STAGE_LOAD(CH_, R0_)                                                                                            \
     {                                                                                                                   \
-        const int c0_ = a.xoff + (CH_) * KC;                                                                            \
         if ((R0_) == 0) {                                                                                               \
-            const char* wsrc_ = (const char*)a.w + (size_t)(nb * a.nchunks + (CH_)) * WBYTES;                           \
-            _Pragma("unroll") for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; pw[i] = *(const uint4*)(wsrc_ + (o < WBYTES ? o : 0)); } \
+            const unsigned wso_ = (unsigned)(nb * a.nchunks + (CH_)) * (unsigned)WBYTES;                                \
+            _Pragma("unroll") for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; pw[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, o < WBYTES ? o : 0, wso_, 0); } \
         }                                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < RND; ++j) {                                                               \
-            const int idx = tid + 256 * ((R0_) + j);                                                                    \
-            const int pix = idx / G, g = idx - pix * G;                                                                 \
-            const int hy = pix / halo_w, hx = pix - hy * halo_w;                                                        \
-            const int iy = iy0 + hy, ix = ix0 + hx;                                                                     \
-            if ((R0_) + j < NPA) {                                                                                      \
-                const bool ok_ = idx < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                           \
-                pa[j] = *(const uint4*)(ok_ ? xg + ((size_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0_ + g * 8 : (const _Float16*)a.zeros); \
-            }                                                                                                           \
-        }                                                                                                               \
+        const unsigned xso_ = (unsigned)(a.xoff + (CH_) * KC) * 2u;                                                     \
+        _Pragma("unroll") for (int j = 0; j < RND; ++j)                                                                 \
+            if ((R0_) + j < NPA) pa[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, aoff[(R0_) + j < NPA ? (R0_) + j : 0], xso_, 0); \
     }
 #define STAGE_STORE(R0_)                                                                                                \
     {                                                                                                                   \
         if ((R0_) == 0) {                                                                                               \
-            _Pragma("unroll") for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; if (o < WBYTES) *(uint4*)(lds_w + o) = pw[i]; } \
+            _Pragma("unroll") for (int i = 0; i < NPW; ++i) { const int o = (tid + 256 * i) * 16; if (o < WBYTES) *(u32x4*)(lds_w + o) = pw[i]; } \
         }                                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < RND; ++j) {                                                               \
-            const int idx = tid + 256 * ((R0_) + j);                                                                    \
-            const int pix = idx / G, g = idx - pix * G;                                                                 \
-            if ((R0_) + j < NPA && idx < ngroups) *(uint4*)(lds_a + pix * PS + g * 16) = pa[j];                         \
-        }                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < RND; ++j)                                                                 \
+            if ((R0_) + j < NPA) *(u32x4*)(lds_a + ldso[(R0_) + j < NPA ? (R0_) + j : 0]) = pa[j];                      \
     }
     if (PIPE) STAGE_LOAD(0, 0)
     for (int ch = 0; ch < a.nchunks; ++ch) {
@@ -844,7 +847,7 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
     if (precision == EAGLE_PREC_F16) {
         const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)hh * hw * f16_ps(c.kc);
         const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 2 + 16);        // output transpose, one strip per wave
-        return conv_ws(c) ? operands + strips + 16 : std::max(operands, strips);
+        return conv_ws(c) ? operands + strips + 16 : std::max(operands + 16, strips);
     }
     return (size_t)c.ks * c.ks * (c.kc / 4) * 4 * bn * 4 + (size_t)hh * hw * (c.kc + 1) * 4;
 }

@@ -880,10 +880,8 @@ static const Inst g_inst[] = {
     ALLNT16(3, 2, 8), ALLNT16(3, 2, 16), ALLNT16(3, 2, 32), ALLNT16(3, 2, 48),
     // 1x1
     ALLNT16(1, 1, 16), ALLNT16(1, 1, 32), ALLNT16(1, 1, 48), ALLNT16(1, 1, 64),
-#ifdef EAGLE_CONV_EXPERIMENTAL
-    // chunk-pipelined staging (variant 2): small chunks only
-    ALLNT16P(3, 1, 16), ALLNT16P(3, 1, 32), ALLNT16P(1, 1, 16), ALLNT16P(1, 1, 32), ALLNT16P(1, 1, 48), ALLNT16P(1, 1, 64),
-#endif
+    // chunk-pipelined staging (variant 2): the next chunk's loads are issued before this chunk's MFMAs; small chunks only
+    ALLNT16P(3, 1, 16), ALLNT16P(3, 1, 32), ALLNT16P(1, 1, 32), ALLNT16P(1, 1, 64),
     // half-size tiles (variant 3): 2 pixel sub-tiles per wave -> fewer registers / less LDS -> more resident workgroups
     ALLNT16H(3, 1, 16), ALLNT16H(3, 1, 32), ALLNT16H(3, 1, 48), ALLNT16H(3, 1, 64), ALLNT16H(3, 2, 8), ALLNT16H(3, 2, 16), ALLNT16H(3, 2, 32), ALLNT16H(1, 1, 16), ALLNT16H(1, 1, 32), ALLNT16H(1, 1, 48), ALLNT16H(1, 1, 64),
     // quarter-size tiles (variant 4): 1 pixel sub-tile per wave

@@ -671,7 +671,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     for (auto& st : nh->s_br) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_fork, hipEventDisableTiming));
     for (auto& e : nh->ev_join) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    nh->multi_stream = !getenv("EAGLE_SINGLE_STREAM");
+    nh->multi_stream = getenv("EAGLE_MULTI_STREAM") != nullptr;   // concurrent HRNet branches: measured slightly slower than one stream once the kernels fill the GPU
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_pre, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_det, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&nh->ev_t0));

@@ -33,12 +33,14 @@ int main(int argc, char** argv)
         hipMemcpy(dw, hw2.data(), 64 << 20, hipMemcpyHostToDevice);
     } hipMemset(db, 0, 1 << 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    static const int kcs[] = {64, 48, 32, 16, 8}, nts[] = {6, 4, 3, 2, 1};
+    static const int kcs[] = {96, 64, 48, 32, 16, 8}, nts[] = {6, 4, 3, 2, 1};
+    static const int variants[] = {0, 2, 3, 4, 6, 7};     // 1, 5 (LDS-DMA) only exist under -DEAGLE_CONV_EXPERIMENTAL
     for (auto& sh : shapes) {
         std::tie(ks, s, cin, cout, h, w, n) = sh;
         const int ho = (h + 2 * (ks / 2) - ks) / s + 1, wo = (w + 2 * (ks / 2) - ks) / s + 1;
-        for (int variant = 0; variant <= 5; ++variant) if (variant != 2) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
+        for (int variant : variants) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
             if (cin % kc || cout % (16 * nt)) continue;
+            if ((variant == 6 || variant == 7) && kc != cin) continue;
             ConvLaunch L;
             L.cfg.ks = ks; L.cfg.stride = s; L.cfg.kc = kc; L.cfg.nt = nt; L.cfg.wx = wx; L.cfg.cin = cin; L.cfg.cout_pad = cout; L.cfg.variant = variant;
             if (!conv_supported(EAGLE_PREC_F16, L.cfg)) continue;
@@ -47,6 +49,7 @@ int main(int argc, char** argv)
             L.x.p = dx; L.x.n = n; L.x.h = h; L.x.w = w; L.x.c = L.x.cs = cin;
             L.y.p = dy; L.y.n = n; L.y.h = ho; L.y.w = wo; L.y.c = L.y.cs = cout;
             L.w = dw; L.bias = (const float*)db; L.post_act = 1;
+            if (ks == 3 && s == 1 && cin == cout) { L.r1 = L.x; }                // BasicBlock-style residual (every second 3x3 of HRNet has one)
             if (getenv("TUNE_VERBOSE")) { fprintf(stderr, "try ks=%d s=%d cin=%d cout=%d h=%d w=%d kc=%d nt=%d wx=%d var=%d lds=%zu\n", ks, s, cin, cout, h, w, kc, nt, wx, variant, conv_lds_bytes(EAGLE_PREC_F16, L.cfg)); fflush(stderr); }
             try {
                 conv_launch(EAGLE_PREC_F16, L, nullptr);

@@ -12,7 +12,7 @@ ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "eo_prims.c")):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("eo_prims.c", "eo_flow.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -148,3 +148,41 @@ def perspective_transform(pts, H):
     out = np.empty_like(pts)
     lib().eo_perspective_transform(_p(pts), pts.shape[0], _p(H, C.c_double), _p(out))
     return out
+
+
+# ---- optical-flow row (eo_flow.c) -------------------------------------------------------------------------------
+def bgr2gray(bgr):
+    """cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY) (cm.py:280)"""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty(bgr.shape[:2], np.uint8)
+    lib().eo_bgr2gray(_p(bgr, C.c_uint8), bgr.shape[0], bgr.shape[1], _p(out, C.c_uint8))
+    return out
+
+
+def bgr2hsv(bgr):
+    """cv2.cvtColor(grid, cv2.COLOR_BGR2HSV) on uint8 (cm.py:459,469,538,545)"""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty(bgr.shape, np.uint8)
+    lib().eo_bgr2hsv(_p(bgr, C.c_uint8), C.c_long(bgr.size // 3), _p(out, C.c_uint8))
+    return out
+
+
+def pyrdown(gray):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().eo_pyrdown(_p(gray, C.c_uint8), h, w, _p(out, C.c_uint8))
+    return out
+
+
+def calc_optical_flow_pyr_lk(prev_gray, next_gray, prev_pts, max_level=2, max_count=10, epsilon=0.03):
+    """cv2.calcOpticalFlowPyrLK(prev_gray, curr_gray, prev_points, None, winSize=(15,15), maxLevel=2,
+    criteria=(EPS|COUNT, 10, 0.03)) (cm.py:65,434) -> (next_pts (n,2) f32, status (n,1) u8)"""
+    prev_gray = np.ascontiguousarray(prev_gray, np.uint8); next_gray = np.ascontiguousarray(next_gray, np.uint8)
+    assert prev_gray.shape == next_gray.shape and prev_gray.ndim == 2
+    pts = _f32(prev_pts).reshape(-1, 2)
+    n = len(pts)
+    nxt = np.zeros((n, 2), np.float32); st = np.zeros((n, 1), np.uint8)
+    lib().eo_calc_optical_flow_pyr_lk(_p(prev_gray, C.c_uint8), _p(next_gray, C.c_uint8), prev_gray.shape[0], prev_gray.shape[1],
+                                      _p(pts), n, max_level, max_count, C.c_double(epsilon), _p(nxt), _p(st, C.c_uint8))
+    return nxt, st

@@ -17,6 +17,9 @@ CLIPS = {
     "cut": (8, 2, 2, [(0, 2 * i) for i in range(5)] + [(3, 40 + 2 * i) for i in range(7)], False),
     # reference default cadence at 25 fps (HRNet every 8th frame, H every 25th): long propagation chains, border losses
     "fps25": (25, 1, 3, [(2, 60 + 4 * i) for i in range(27)], False),
+    # a black frame on an unscheduled index: every point loses its status -> empty flow -> on-demand detection (cm.py:316-319);
+    # the sparse detection on the next unscheduled index after it keeps the chain short
+    "blackout": (8, 2, 2, [(0, 0), (0, 2), (-1, 4), (0, 6), (0, 8), (0, 10), (-1, 12), (-1, 14), (0, 16), (0, 18)], False),
     # brightness calibration on
     "calib": (6, 1, 2, [(4, 3 * i) for i in range(7)], True),
 }
@@ -25,7 +28,7 @@ CLIPS = {
 def frames_of(name):
     fr = []
     for i, (seed, t) in enumerate(CLIPS[name][3]):
-        f = synth.frame(seed, t).copy()
+        f = synth.frame(seed, t).copy() if seed >= 0 else np.zeros((720, 1280, 3), np.uint8)
         f[0, 0, 0] = i
         fr.append(f)
     return fr
@@ -34,10 +37,10 @@ def frames_of(name):
 def canned(name):
     """-> (kps per frame: list of (heat-map index, x_n, y_n, score), dets per frame: (n,6) float32)"""
     spec = CLIPS[name][3]
-    rng = np.random.default_rng(abs(hash(name)) % 1000 if False else sum(map(ord, name)))
+    rng = np.random.default_rng(sum(map(ord, name)))
     kps, dets = [], []
     for i, (seed, t) in enumerate(spec):
-        vis = synth.visible_landmarks(seed, t)
+        vis = synth.visible_landmarks(max(seed, 0), t)
         kp = []
         for idx, (x, y) in sorted(vis.items()):
             if rng.random() < 0.8:
@@ -48,6 +51,8 @@ def canned(name):
             kp = kp[: 2 + i]
         if name == "cut" and i == 8:
             kp = kp[:2]
+        if name == "blackout" and i in (6, 7):
+            kp = kp[:3]
         nd = int(rng.integers(0, 30))
         d = np.zeros((nd, 6), np.float32)
         d[:, 0] = rng.uniform(-5, 1250, nd); d[:, 1] = rng.uniform(-5, 690, nd)

@@ -11,6 +11,9 @@ the GPU box).  Usage:  PYTHONPATH=/root/repo python tests/golden/make_golden.py
    while cv2.findHomography / perspectiveTransform / fitLine are served by this repo's restatements
    (oracle/eo_prims.c) and the two networks by canned outputs.  Pins rows a4, a5 (minus fitLine), a9, a10 (point
    selection + inlier filtering), a11, a12, a13 of the host-logic oracle.
+4. flow_golden.json    — the reference's own loop with keypoint_interval > 1 (optical-flow propagation, first-frame forward search,
+   on-demand detection, calibration; cm.py:188-331, 419-478, 520-555) on the synthetic clips of tests/flow_cases.py, with
+   cv2.cvtColor / calcOpticalFlowPyrLK served by oracle/eo_flow.c.  Pins the control logic of SURVEY §8f row 2.
 Only data (inputs + expected outputs) is written; no reference source text is stored."""
 import importlib.util
 import json
@@ -78,7 +81,11 @@ def install_stubs():
     cv2.COLOR_BGR2RGB, cv2.COLOR_BGR2GRAY, cv2.COLOR_BGR2HSV = 4, 6, 40
     cv2.RANSAC, cv2.RHO, cv2.LMEDS, cv2.DIST_L2 = 8, 16, 4, 2
     cv2.TERM_CRITERIA_EPS, cv2.TERM_CRITERIA_COUNT = 2, 1
-    cv2.cvtColor = lambda img, code: img[..., 0] if code == 6 else img
+    # BGR2GRAY / BGR2HSV are served by the oracle's restatements (eo_flow.c); BGR2RGB leaves the frame alone so that the
+    # canned-network stubs can read the frame index from pixel [0,0,0]
+    cv2.cvtColor = lambda img, code: P.bgr2gray(img) if code == 6 else (P.bgr2hsv(img) if code == 40 else img)
+    cv2.calcOpticalFlowPyrLK = lambda prev, cur, pts, nxt, winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03): (
+        *P.calc_optical_flow_pyr_lk(prev, cur, pts, maxLevel, criteria[1], criteria[2]), None)
 
     def find_h(src, dst, method, thr=None):
         if method != 8:
@@ -210,8 +217,55 @@ def dump_cadence():
     print("cadence golden:", [(i, r["Boundaries"][0] is not None, len(r["Keypoints"])) for i, r in sorted(res.items())])
 
 
+def _jsonable(o):
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    if isinstance(o, np.integer):
+        return int(o)
+    return float(o)
+
+
+def dump_flow():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import flow_cases
+    cm = sys.modules["eagle.models.coordinate_model"]
+    out = {}
+    for name, (fps, nh, nk, spec, calib) in flow_cases.CLIPS.items():
+        frames = flow_cases.frames_of(name)
+        kps, dets = flow_cases.canned(name)
+        m = object.__new__(cm.CoordinateModel)
+        m.device = "cpu"
+        m.class_names = {0: "Player", 1: "Goalkeeper", 2: "Ball", 3: "Referee", 4: "Staff members"}
+        m.keypoint_conf, m.detector_conf = 0.3, 0.35
+        m.lk_params = dict(winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.03))
+        m.transforms = lambda image: {"image": torch.full((3, 4, 4), float(image[0, 0, 0]))}
+        calls = []
+        km = types.SimpleNamespace()
+        km.unnormalized_model = [None, types.SimpleNamespace(weight=types.SimpleNamespace(data=torch.zeros(1)))]
+
+        def get_keypoints(x, kps=kps, calls=calls):
+            calls.extend(int(x[b, 0, 0, 0]) for b in range(x.shape[0]))
+            return [list(kps[int(x[b, 0, 0, 0])]) for b in range(x.shape[0])]
+
+        km.get_keypoints = get_keypoints
+        m.keypoint_model = km
+        m.detector_model = lambda frame, verbose=False, conf=0.15, dets=dets: [types.SimpleNamespace(boxes=_Boxes(dets[int(frame[0, 0, 0])]))]
+        m.tracker = types.SimpleNamespace(update=lambda d, f: np.zeros((0, 8)))
+        try:
+            res = m.get_coordinates(frames, fps, num_homography=nh, num_keypoint_detection=nk, verbose=False, calibration=calib)
+            rec = json.loads(json.dumps(res, default=_jsonable))
+            err = None
+        except Exception as e:                       # the reference's own exception (calibration near the image border)
+            rec, err = None, type(e).__name__
+        out[name] = {"records": rec, "raises": err, "detected_frames": sorted(set(calls))}
+        print("flow golden:", name, err or [(i, len(r["Keypoints"]), r["Boundaries"][0] is not None) for i, r in sorted(res.items())],
+              "detect on", sorted(set(calls)))
+    json.dump(out, open(f"{HERE}/flow_golden.json", "w"))
+
+
 if __name__ == "__main__":
     dump_pitch()
     dump_hrnet()
     dump_loop()
     dump_cadence()
+    dump_flow()

@@ -104,4 +104,38 @@ void reproject_launch(EagleFrameResult* d_recs, const double* d_Hs, const unsign
 void homography_only_launch(const float* d_img, const float* d_world, int npts, double thresh, int max_iters, int lm_iters,
                             double* d_H, uint8_t* d_mask, int* d_ok, hipStream_t s);
 
+
+// ---- optical-flow key-point cadence (cm.py:188-331, 419-478, 520-555) ---------------------------
+// A clip resident in HBM: the caller's BGR frames plus the gray pyramid of every frame (flow.hip, K11).
+struct ClipView {
+    const uint8_t* bgr = nullptr;
+    const uint8_t* g[3] = {nullptr, nullptr, nullptr};
+    int lh[3] = {0, 0, 0}, lw[3] = {0, 0, 0};
+    int levels = 0;          // highest pyramid level in use (cv2 maxLevel 2, fewer for tiny frames)
+    int n = 0, h = 0, w = 0;
+};
+// mem[i] of the reference loop (cm.py:211): the key-points a model detection (or the first-frame search) produced for frame i,
+// in dict order.  n = -1: no entry.
+struct MemList { int n; EagleFlowKp kp[EAGLE_N_LANDMARKS]; };
+// The loop-carried state of cm.py:207-213 plus the scratch of the current optical-flow step.
+struct ChainState {
+    int n_prev; EagleFlowKp prev[EAGLE_N_LANDMARKS];       // prev_keypoints, dict order
+    int has_H, compute_h; double H[9];                      // homography_matrix, compute_homography
+    int stalled;                                            // frame waiting for an on-demand detection (cm.py:317), or -1
+    int error;                                              // 1 + frame at which the reference raises (calibration, cm.py:545)
+    int lk_valid, lk_n;                                     // this step ran a flow; number of points it tracked
+    float lk_prev[2 * EAGLE_N_LANDMARKS], lk_next[2 * EAGLE_N_LANDMARKS];
+    unsigned char lk_status[EAGLE_N_LANDMARKS];
+    int flow_n; EagleFlowKp flow[EAGLE_N_LANDMARKS];       // operator mode: the filtered dict calculate_optical_flow returns
+};
+void gray_pyramid_launch(const uint8_t* d_bgr, int n, int h, int w, uint8_t* g0, uint8_t* g1, uint8_t* g2, hipStream_t s);
+void lk_launch(const ClipView& cv, int src_frame, int dst_frame, ChainState* st, const MemList* mem, int kint, hipStream_t s);
+// heat-map maxima of `n` frames -> mem[first + k*stride] (threshold / pixel mapping / dedup, cm.py:231-251, 500-518)
+void decode_mem_launch(const ArgmaxPart* parts, int n, const PostParams& pp, MemList* mem, int first, int stride, hipStream_t s);
+// one iteration of the reference loop body for frame `frame` in any cadence (runs after lk_launch of the same frame)
+void chain_launch(const ClipView& cv, ChainState* st, const MemList* mem, EagleFrameResult* recs, const PostParams& pp, int frame,
+                  int kint, int hint, int calib, hipStream_t s);
+// calculate_optical_flow as an operator: filters the flow of lk_launch(src, dst) with hue grids of frame `hue_frame` into st->flow
+void flow_filter_launch(const ClipView& cv, ChainState* st, int hue_frame, hipStream_t s);
+
 }  // namespace eagle

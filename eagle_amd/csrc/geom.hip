@@ -585,6 +585,136 @@ __device__ bool find_x_at_y(double x1, double y1, double x2, double y2, double y
     return true;
 }
 
+// (2) threshold / pixel mapping / same-pixel dedup (kh.py:590-593, cm.py:500-518 == cm.py:231-251): heat-map maxima -> kp[0..n)
+__device__ int decode_dedup(const int* hm_idx, const float* hm_score, const PostParams& pp, EagleKeypoint* kp)
+{
+    int lx[57], ly[57], q[57], nq = 0;
+    for (int i = 0; i < 57; ++i) {
+        const double s = (double)hm_score[i];
+        if (!(s > 0.01)) continue;
+        if (s < pp.keypoint_conf) continue;
+        const int py = hm_idx[i] / pp.hm_w, px = hm_idx[i] - py * pp.hm_w;
+        const double xn = (double)px / (double)(pp.hm_w - 1 > 1 ? pp.hm_w - 1 : 1);
+        const double yn = (double)py / (double)(pp.hm_h - 1 > 1 ? pp.hm_h - 1 : 1);
+        lx[i] = (int)(xn * (double)pp.frame_w); ly[i] = (int)(yn * (double)pp.frame_h);
+        q[nq++] = i;
+    }
+    int nkp = 0;
+    for (int a_ = 0; a_ < nq; ++a_) {
+        const int i = q[a_];
+        int count = 0; float mx = -1.f;
+        for (int b_ = 0; b_ < nq; ++b_) {
+            const int j = q[b_];
+            if (lx[j] == lx[i] && ly[j] == ly[i]) { ++count; mx = hm_score[j] > mx ? hm_score[j] : mx; }
+        }
+        if (count > 1 && hm_score[i] != mx) continue;
+        int slot = -1;
+        for (int k = 0; k < nkp; ++k) if (kp[k].x == lx[i] && kp[k].y == ly[i]) slot = k;
+        if (slot < 0) slot = nkp++;
+        EagleKeypoint e; e.label = i; e.x = lx[i]; e.y = ly[i]; e.score = hm_score[i];
+        e.synthesized = 0; e.on_plane = 0; e.inlier = 0; e.pad = 0;
+        kp[slot] = e;
+    }
+    return nkp;
+}
+
+// (3) synthesis by line intersection (cm.py:140-186); appends to kp[0..nkp) and returns the new count
+__device__ int synthesize_keypoints(EagleKeypoint* kp, int nkp)
+{
+    signed char slot_of[57];
+    for (int i = 0; i < 57; ++i) slot_of[i] = -1;
+    for (int k = 0; k < nkp; ++k) slot_of[kp[k].label] = (signed char)k;
+    static_assert(PT_NY == PT_NX, "one table shape for both line families");
+    double lines[2][PT_NY][4];                           // [0]: lines of constant world y, [1]: of constant world x
+    int lok[2][PT_NY];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int g = 0; g < PT_NY; ++g) {
+            float pts[2 * PT_MAXG]; int np = 0;
+            for (int m = 0; m < PT_MAXG; ++m) {
+                const int lab = pass == 0 ? PT_YGROUP[g][m] : PT_XGROUP[g][m];
+                if (lab < 0) break;
+                if (PT_NOT_ON_PLANE_IDX[lab]) continue;
+                const int sl = slot_of[lab];
+                if (sl < 0) continue;
+                pts[2 * np] = (float)kp[sl].x; pts[2 * np + 1] = (float)kp[sl].y; ++np;
+            }
+            double line[4] = {0, 0, 0, 0};
+            lok[pass][g] = (np >= 2 && fit_line(pts, np, line)) ? 1 : 0;
+            for (int k = 0; k < 4; ++k) lines[pass][g][k] = line[k];
+        }
+    }
+    int added = 0;
+    for (int gy = 0; gy < PT_NY && added < 30; ++gy) {
+        if (!lok[0][gy]) continue;
+        for (int gx = 0; gx < PT_NX; ++gx) {
+            if (!lok[1][gx]) continue;
+            const int lab = PT_CROSS[gy][gx];
+            if (lab < 0 || slot_of[lab] >= 0) continue;
+            double px, py;
+            if (!intersect_lines(lines[0][gy], lines[1][gx], &px, &py)) continue;
+            EagleKeypoint e; e.label = lab; e.x = (int)rint(px); e.y = (int)rint(py); e.score = 0.f;
+            e.synthesized = 1; e.on_plane = 0; e.inlier = 0; e.pad = 0;
+            slot_of[lab] = (signed char)nkp;
+            kp[nkp++] = e;
+            if (++added >= 30) break;
+        }
+    }
+    return nkp;
+}
+
+// (4) on-plane selection (cm.py:338-349): float32 image and world points
+__device__ int select_plane_points(EagleKeypoint* kp, int nkp, float* img, float* world, int* used)
+{
+    int np = 0;
+    for (int k = 0; k < nkp; ++k) {
+        const int lab = kp[k].label;
+        if (!PT_ON_PLANE[lab]) continue;
+        kp[k].on_plane = 1;
+        img[2 * np] = (float)kp[k].x; img[2 * np + 1] = (float)kp[k].y;
+        world[2 * np] = (float)PT_WORLD[lab][0]; world[2 * np + 1] = (float)PT_WORLD[lab][1];
+        used[np] = k; ++np;
+    }
+    return np;
+}
+
+// (7) boundaries (cm.py:396-414)
+__device__ void write_bounds(EagleFrameResult* R, const double* H, bool Hok, int frame_h, int frame_w)
+{
+    bool bok = false;
+    double bx[4] = {0, 0, 0, 0};
+    if (Hok) {
+        float cx[4], cy[4];
+        persp(H, 0.f, 0.f, &cx[0], &cy[0]);
+        persp(H, (float)frame_w, 0.f, &cx[1], &cy[1]);
+        persp(H, 0.f, (float)frame_h, &cx[2], &cy[2]);
+        persp(H, (float)frame_w, (float)frame_h, &cx[3], &cy[3]);
+        const double tlx = (int)cx[0], tly = (int)cy[0], trx = (int)cx[1], try_ = (int)cy[1];
+        const double blx = (int)cx[2], bly = (int)cy[2], brx = (int)cx[3], bry = (int)cy[3];
+        double ntl, ntr, nbl, nbr;
+        bok = find_x_at_y(tlx, tly, blx, bly, 68.0, &ntl) && find_x_at_y(trx, try_, brx, bry, 68.0, &ntr) &&
+              find_x_at_y(blx, bly, ntl, 68.0, 0.0, &nbl) && find_x_at_y(brx, bry, ntr, 68.0, 0.0, &nbr);
+        if (bok) { bx[0] = nbl; bx[1] = ntl; bx[2] = ntr; bx[3] = nbr; }
+    }
+    R->bounds_valid = bok;
+    for (int k = 0; k < 4; ++k) R->bounds[k] = bx[k];
+}
+
+// (6) projection of foot points (cm.py:369-392); all threads
+__device__ void project_detections(EagleFrameResult* R, const double* H, bool Hok, int tid)
+{
+    const int nd = R->n_det;
+    for (int k = tid; k < nd; k += POST_T) {
+        EagleDet* d = &R->det[k];
+        float ox = 0.f, oy = 0.f; int tx = 0, ty = 0; unsigned char inb = 0;
+        if (Hok) {
+            persp(H, (float)d->foot_x, (float)d->foot_y, &ox, &oy);
+            tx = (int)ox; ty = (int)oy;
+            inb = !(tx < 0 || tx > 105 || ty < 0 || ty > 68);
+        }
+        d->pitch_xf = ox; d->pitch_yf = oy; d->pitch_x = tx; d->pitch_y = ty; d->in_bounds = inb;
+    }
+}
+
 __global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -606,89 +736,10 @@ __global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
     __syncthreads();
 
     if (tid == 0) {
-        // (2) threshold / pixel mapping / same-pixel dedup (kh.py:590-593, cm.py:500-518)
-        int lx[57], ly[57], q[57], nq = 0;
-        for (int i = 0; i < 57; ++i) {
-            const double s = (double)S.hm_score[i];
-            if (!(s > 0.01)) continue;
-            if (s < pp.keypoint_conf) continue;
-            const int py = S.hm_idx[i] / pp.hm_w, px = S.hm_idx[i] - py * pp.hm_w;
-            const double xn = (double)px / (double)(pp.hm_w - 1 > 1 ? pp.hm_w - 1 : 1);
-            const double yn = (double)py / (double)(pp.hm_h - 1 > 1 ? pp.hm_h - 1 : 1);
-            lx[i] = (int)(xn * (double)pp.frame_w); ly[i] = (int)(yn * (double)pp.frame_h);
-            q[nq++] = i;
-        }
-        int nkp = 0;
-        for (int a_ = 0; a_ < nq; ++a_) {
-            const int i = q[a_];
-            int count = 0; float mx = -1.f;
-            for (int b_ = 0; b_ < nq; ++b_) {
-                const int j = q[b_];
-                if (lx[j] == lx[i] && ly[j] == ly[i]) { ++count; mx = S.hm_score[j] > mx ? S.hm_score[j] : mx; }
-            }
-            if (count > 1 && S.hm_score[i] != mx) continue;
-            int slot = -1;
-            for (int k = 0; k < nkp; ++k) if (S.kp[k].x == lx[i] && S.kp[k].y == ly[i]) slot = k;
-            if (slot < 0) slot = nkp++;
-            EagleKeypoint kp; kp.label = i; kp.x = lx[i]; kp.y = ly[i]; kp.score = S.hm_score[i];
-            kp.synthesized = 0; kp.on_plane = 0; kp.inlier = 0; kp.pad = 0;
-            S.kp[slot] = kp;
-        }
-        // (3) synthesis by line intersection (cm.py:140-186), only with >= 2 keypoints (cm.py:326)
-        if (nkp >= 2) {
-            signed char slot_of[57];
-            for (int i = 0; i < 57; ++i) slot_of[i] = -1;
-            for (int k = 0; k < nkp; ++k) slot_of[S.kp[k].label] = (signed char)k;
-            double ylines[PT_NY][4], xlines[PT_NX][4];
-            bool yok[PT_NY], xok[PT_NX];
-            for (int pass = 0; pass < 2; ++pass) {
-                const int ng = pass == 0 ? PT_NY : PT_NX;
-                for (int g = 0; g < ng; ++g) {
-                    float pts[2 * PT_MAXG]; int np = 0;
-                    for (int m = 0; m < PT_MAXG; ++m) {
-                        const int lab = pass == 0 ? PT_YGROUP[g][m] : PT_XGROUP[g][m];
-                        if (lab < 0) break;
-                        if (PT_NOT_ON_PLANE_IDX[lab]) continue;
-                        const int sl = slot_of[lab];
-                        if (sl < 0) continue;
-                        pts[2 * np] = (float)S.kp[sl].x; pts[2 * np + 1] = (float)S.kp[sl].y; ++np;
-                    }
-                    bool ok = false;
-                    double line[4] = {0, 0, 0, 0};
-                    if (np >= 2) ok = fit_line(pts, np, line);
-                    if (pass == 0) { yok[g] = ok; for (int k = 0; k < 4; ++k) ylines[g][k] = line[k]; }
-                    else { xok[g] = ok; for (int k = 0; k < 4; ++k) xlines[g][k] = line[k]; }
-                }
-            }
-            int added = 0;
-            for (int gy = 0; gy < PT_NY && added < 30; ++gy) {
-                if (!yok[gy]) continue;
-                for (int gx = 0; gx < PT_NX; ++gx) {
-                    if (!xok[gx]) continue;
-                    const int lab = PT_CROSS[gy][gx];
-                    if (lab < 0 || slot_of[lab] >= 0) continue;
-                    double px, py;
-                    if (!intersect_lines(ylines[gy], xlines[gx], &px, &py)) continue;
-                    EagleKeypoint kp; kp.label = lab; kp.x = (int)rint(px); kp.y = (int)rint(py); kp.score = 0.f;
-                    kp.synthesized = 1; kp.on_plane = 0; kp.inlier = 0; kp.pad = 0;
-                    slot_of[lab] = (signed char)nkp;
-                    S.kp[nkp++] = kp;
-                    if (++added >= 30) break;
-                }
-            }
-        }
+        int nkp = decode_dedup(S.hm_idx, S.hm_score, pp, S.kp);
+        if (nkp >= 2) nkp = synthesize_keypoints(S.kp, nkp);          // cm.py:326
         S.nkp = nkp;
-        // (4) on-plane selection (cm.py:338-349): float32 image and world points
-        int np = 0;
-        for (int k = 0; k < nkp; ++k) {
-            const int lab = S.kp[k].label;
-            if (!PT_ON_PLANE[lab]) continue;
-            S.kp[k].on_plane = 1;
-            S.img[2 * np] = (float)S.kp[k].x; S.img[2 * np + 1] = (float)S.kp[k].y;
-            S.world[2 * np] = (float)PT_WORLD[lab][0]; S.world[2 * np + 1] = (float)PT_WORLD[lab][1];
-            S.used[np] = k; ++np;
-        }
-        S.npts = np;
+        S.npts = select_plane_points(S.kp, nkp, S.img, S.world, S.used);
     }
     __syncthreads();
 
@@ -698,41 +749,277 @@ __global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
     const bool Hok = S.npts >= 4 && S.hs.ok;
     if (tid == 0) {
         for (int k = 0; k < 9; ++k) { S.H[k] = Hok ? S.hs.best[k] : 0.0; R->H[k] = S.H[k]; }
-        R->H_valid = Hok; R->pad[0] = R->pad[1] = 0;
+        R->H_valid = Hok; R->pad[0] = Hok; R->pad[1] = 0;
         if (Hok) for (int i = 0; i < S.npts; ++i) S.kp[S.used[i]].inlier = S.hs.mask[i];
         R->n_kp = S.nkp;
-        // (7) boundaries (cm.py:396-414)
-        bool bok = false;
-        double bx[4] = {0, 0, 0, 0};
-        if (Hok) {
-            float cx[4], cy[4];
-            persp(S.H, 0.f, 0.f, &cx[0], &cy[0]);
-            persp(S.H, (float)pp.frame_w, 0.f, &cx[1], &cy[1]);
-            persp(S.H, 0.f, (float)pp.frame_h, &cx[2], &cy[2]);
-            persp(S.H, (float)pp.frame_w, (float)pp.frame_h, &cx[3], &cy[3]);
-            const double tlx = (int)cx[0], tly = (int)cy[0], trx = (int)cx[1], try_ = (int)cy[1];
-            const double blx = (int)cx[2], bly = (int)cy[2], brx = (int)cx[3], bry = (int)cy[3];
-            double ntl, ntr, nbl, nbr;
-            bok = find_x_at_y(tlx, tly, blx, bly, 68.0, &ntl) && find_x_at_y(trx, try_, brx, bry, 68.0, &ntr) &&
-                  find_x_at_y(blx, bly, ntl, 68.0, 0.0, &nbl) && find_x_at_y(brx, bry, ntr, 68.0, 0.0, &nbr);
-            if (bok) { bx[0] = nbl; bx[1] = ntl; bx[2] = ntr; bx[3] = nbr; }
-        }
-        R->bounds_valid = bok;
-        for (int k = 0; k < 4; ++k) R->bounds[k] = bx[k];
+        write_bounds(R, S.H, Hok, pp.frame_h, pp.frame_w);
     }
     __syncthreads();
     for (int k = tid; k < S.nkp; k += POST_T) R->kp[k] = S.kp[k];
-    // (6) projection of foot points (cm.py:369-392)
-    const int nd = R->n_det;
-    for (int k = tid; k < nd; k += POST_T) {
-        EagleDet* d = &R->det[k];
-        float ox = 0.f, oy = 0.f; int tx = 0, ty = 0; unsigned char inb = 0;
-        if (Hok) {
-            persp(S.H, (float)d->foot_x, (float)d->foot_y, &ox, &oy);
-            tx = (int)ox; ty = (int)oy;
-            inb = !(tx < 0 || tx > 105 || ty < 0 || ty > 68);
+    project_detections(R, S.H, Hok, tid);
+}
+
+// ---- the loop body in any cadence ---------------------------------------------------------------------
+// cv2.cvtColor(grid, COLOR_BGR2HSV)[..., 0] of one 8-bit pixel (hue range 180, table-driven fixed point, hsv_shift 12)
+__device__ __forceinline__ int hue180(int b, int g, int r)
+{
+    int v = b, vmin = b;
+    if (g > v) v = g; if (r > v) v = r;
+    if (g < vmin) vmin = g; if (r < vmin) vmin = r;
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    const int hdiv = diff ? (int)rint((double)(180 << 12) / (6. * (double)diff)) : 0;
+    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    hh = (hh * hdiv + (1 << 11)) >> 12;
+    hh += hh < 0 ? 180 : 0;
+    return hh & 255;
+}
+
+// np.mean(hsv[y-1:y+2, x-1:x+2, 0]) around a float32 point truncated to int and clipped into the frame (cm.py:452-470)
+__device__ double hue_mean_at(const uint8_t* frame, int h, int w, float fx, float fy)
+{
+    int x = (int)fx, y = (int)fy;
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x); y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+    const int x0 = x - 1 > 0 ? x - 1 : 0, x1 = x + 2 < w ? x + 2 : w, y0 = y - 1 > 0 ? y - 1 : 0, y1 = y + 2 < h ? y + 2 : h;
+    int sum = 0;
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) {
+            const uint8_t* p = frame + ((size_t)yy * w + xx) * 3;
+            sum += hue180(p[0], p[1], p[2]);
         }
-        d->pitch_xf = ox; d->pitch_yf = oy; d->pitch_x = tx; d->pitch_y = ty; d->in_bounds = inb;
+    return (double)sum / (double)((y1 - y0) * (x1 - x0));
+}
+
+// float32 add.reduce in numpy's order (pairwise sum, n <= 128: eight running partial sums, then the tail)
+__device__ float np_sum_f32(const float* a, int n)
+{
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    float r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+struct FlowShared {
+    double hue[2 * EAGLE_N_LANDMARKS];     // [2*p] around the new point, [2*p+1] around the previous point
+    float move[EAGLE_N_LANDMARKS], sq[EAGLE_N_LANDMARKS];
+    int surv[EAGLE_N_LANDMARKS];
+    EagleKeypoint flow[EAGLE_N_LANDMARKS]; int nflow;
+};
+
+// calculate_optical_flow after the cv2 call (cm.py:438-478): status filter, z-score filter, hue filter; -> F.flow in dict order.
+// Row j of the surviving points is labelled with the j-th key of the UNFILTERED dict (cm.py:446), as the reference does.
+__device__ void flow_filter_block(FlowShared& F, const ChainState* st, const uint8_t* frame, int h, int w, int tid)
+{
+    const int n = st->lk_n;
+    for (int t = tid; t < 2 * n; t += POST_T) {
+        const int p = t >> 1;
+        const float* q = (t & 1) ? st->lk_prev : st->lk_next;
+        F.hue[t] = hue_mean_at(frame, h, w, q[2 * p], q[2 * p + 1]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int p = 0; p < n; ++p)
+            if (st->lk_status[p]) {
+                const float dx = st->lk_next[2 * p] - st->lk_prev[2 * p], dy = st->lk_next[2 * p + 1] - st->lk_prev[2 * p + 1];
+                const float sx = dx * dx, sy = dy * dy;
+                F.move[c] = sqrtf(sx + sy);                        // np.linalg.norm(axis=1) on float32
+                F.surv[c++] = p;
+            }
+        int nf = 0;
+        if (c > 0) {
+            const float mean = np_sum_f32(F.move, c) / (float)c;   // np.mean / np.std on float32 (numpy 2 scalar rules: stays float32)
+            for (int j = 0; j < c; ++j) { const float d = F.move[j] - mean; F.sq[j] = d * d; }
+            const float sd = sqrtf(np_sum_f32(F.sq, c) / (float)c) + 1e-6f;
+            for (int j = 0; j < c; ++j) {
+                const int p = F.surv[j];
+                const float z = (F.move[j] - mean) / sd;
+                if (z > 2.f) continue;
+                if (fabs(F.hue[2 * p] - F.hue[2 * p + 1]) > 25.0) continue;
+                EagleKeypoint e; e.label = st->prev[j].label;      // keys[j] of the unfiltered dict
+                e.x = (int)st->lk_next[2 * p]; e.y = (int)st->lk_next[2 * p + 1]; e.score = 0.f;
+                e.synthesized = 0; e.on_plane = 0; e.inlier = 0; e.pad = 1;
+                F.flow[nf++] = e;
+            }
+        }
+        F.nflow = nf;
+    }
+    __syncthreads();
+}
+
+// {**dst, **src}: values of src win, new keys are appended in src order
+__device__ int dict_merge(EagleKeypoint* dst, int nd, const EagleKeypoint* src, int ns)
+{
+    for (int s = 0; s < ns; ++s) {
+        int slot = -1;
+        for (int k = 0; k < nd; ++k) if (dst[k].label == src[s].label) { slot = k; break; }
+        if (slot < 0) slot = nd++;
+        dst[slot] = src[s];
+    }
+    return nd;
+}
+
+__device__ int mem_to_kp(const MemList& m, EagleKeypoint* out)
+{
+    for (int k = 0; k < m.n; ++k) {
+        EagleKeypoint e; e.label = m.kp[k].label; e.x = m.kp[k].x; e.y = m.kp[k].y; e.score = m.kp[k].score;
+        e.synthesized = 0; e.on_plane = 0; e.inlier = 0; e.pad = 0;
+        out[k] = e;
+    }
+    return m.n > 0 ? m.n : 0;
+}
+
+// calibrate_keypoints (cm.py:520-555): move a dark key-point to the brightest pixel (V = max(B,G,R)) of the 6x6 grid around it.
+// Returns false where the reference raises IndexError (grid_hsv[3, 3] of a grid clipped to fewer than 4 rows or columns).
+__device__ bool calibrate_keypoints(EagleKeypoint* kp, int nkp, const uint8_t* frame, int h, int w)
+{
+    for (int k = 0; k < nkp; ++k) {
+        const int x = kp[k].x, y = kp[k].y;
+        if (!(0 <= x && x < w && 0 <= y && y < h)) continue;
+        const uint8_t* p = frame + ((size_t)y * w + x) * 3;
+        int v = p[0] > p[1] ? p[0] : p[1]; v = v > p[2] ? v : p[2];
+        if (v >= 150) continue;
+        const int x0 = x - 3 > 0 ? x - 3 : 0, x1 = x + 3 < w ? x + 3 : w, y0 = y - 3 > 0 ? y - 3 : 0, y1 = y + 3 < h ? y + 3 : h;
+        if (y1 - y0 < 4 || x1 - x0 < 4) return false;
+        int best = -1, bx = 0, by = 0;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) {
+                const uint8_t* q = frame + ((size_t)yy * w + xx) * 3;
+                int vv = q[0] > q[1] ? q[0] : q[1]; vv = vv > q[2] ? vv : q[2];
+                if (vv > best) { best = vv; bx = xx - x0; by = yy - y0; }
+            }
+        int ax = x + bx - 3, ay = y + by - 3;
+        ax = ax < 0 ? 0 : (ax > w - 1 ? w - 1 : ax); ay = ay < 0 ? 0 : (ay > h - 1 ? h - 1 : ay);
+        kp[k].x = ax; kp[k].y = ay;
+    }
+    return true;
+}
+
+struct ChainShared { PostShared P; FlowShared F; EagleKeypoint tmp[EAGLE_N_LANDMARKS]; int attempt, own, stop; };
+struct ChainArgs { ClipView cv; ChainState* st; const MemList* mem; EagleFrameResult* recs; PostParams pp; const unsigned* rng_raw; int frame, kint, hint, calib; };
+
+__global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ChainShared& C = *(ChainShared*)smem;
+    PostShared& S = C.P;
+    ChainState* st = a.st;
+    const int tid = threadIdx.x, i = a.frame;
+    if (st->stalled >= 0 || st->error) return;
+    const PostParams& pp = a.pp;
+    EagleFrameResult* R = a.recs + i;
+    const uint8_t* frame = a.cv.bgr + (size_t)i * a.cv.h * a.cv.w * 3;
+    const bool have_flow = st->lk_valid != 0;
+    if (have_flow) flow_filter_block(C.F, st, frame, a.cv.h, a.cv.w, tid);
+    if (tid == 0) {
+        // key-points of this frame (cm.py:282-324)
+        const MemList& M = a.mem[i];
+        const int nf = have_flow ? C.F.nflow : 0;
+        const bool scheduled = i == 0 || i % a.kint == 0;
+        int nkp = 0, stop = 0;
+        if (scheduled) {
+            if (M.n < 0) stop = 1;                                   // the caller detects scheduled frames up front
+            else {
+                nkp = mem_to_kp(M, S.kp);
+                if (M.n < 4 && i > 0) nkp = dict_merge(S.kp, nkp, C.F.flow, nf);           // {**keypoints, **optical_flow_keypoints}
+            }
+        } else if (nf < 4) {
+            if (M.n < 0) stop = 1;                                   // on-demand detection (cm.py:317)
+            else { nkp = mem_to_kp(M, S.kp); nkp = dict_merge(S.kp, nkp, C.F.flow, nf); }
+        } else {
+            for (int k = 0; k < nf; ++k) S.kp[k] = C.F.flow[k];
+            nkp = nf;
+        }
+        if (!stop) {
+            if (M.n >= 0) { const int nm = mem_to_kp(M, C.tmp); nkp = dict_merge(S.kp, nkp, C.tmp, nm); }   // {**keypoints, **mem.get(i, {})}
+            if (nkp >= 2) nkp = synthesize_keypoints(S.kp, nkp);
+            if (a.calib && !calibrate_keypoints(S.kp, nkp, frame, a.cv.h, a.cv.w)) { st->error = 1 + i; stop = 2; }
+        }
+        if (stop == 1) st->stalled = i;
+        if (!stop) {
+            S.nkp = nkp;
+            st->n_prev = nkp;                                        // prev_keypoints = keypoints (cm.py:329)
+            for (int k = 0; k < nkp; ++k) { EagleFlowKp e; e.label = S.kp[k].label; e.x = S.kp[k].x; e.y = S.kp[k].y; e.score = S.kp[k].score; st->prev[k] = e; }
+            C.attempt = (i % a.hint == 0) || st->compute_h;
+            S.npts = C.attempt ? select_plane_points(S.kp, nkp, S.img, S.world, S.used) : 0;
+        }
+        C.stop = stop;
+    }
+    __syncthreads();
+    if (C.stop) return;
+    if (C.attempt) {
+        find_homography_block(S.hs, a.rng_raw, S.img, S.world, S.npts, pp.ransac_thresh, pp.ransac_max_iters, pp.lm_iters);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int own = 0;
+        if (C.attempt) {
+            if (S.npts >= 4 && S.hs.ok) {                            // cm.py:358-365
+                own = 1;
+                int np_ = 0;
+                for (int k = 0; k < S.npts; ++k) {
+                    S.kp[S.used[k]].inlier = S.hs.mask[k];
+                    if (S.hs.mask[k]) { const EagleKeypoint& q = S.kp[S.used[k]]; EagleFlowKp e; e.label = q.label; e.x = q.x; e.y = q.y; e.score = q.score; st->prev[np_++] = e; }
+                }
+                st->n_prev = np_;
+                for (int k = 0; k < 9; ++k) st->H[k] = S.hs.best[k];
+                st->has_H = 1; st->compute_h = 0;
+            } else st->compute_h = 1;
+        }
+        const bool Hok = st->has_H != 0;
+        for (int k = 0; k < 9; ++k) { S.H[k] = Hok ? st->H[k] : 0.0; R->H[k] = S.H[k]; }
+        S.H_ok = Hok;
+        R->H_valid = Hok; R->pad[0] = (uint8_t)own; R->pad[1] = 0;
+        R->n_kp = S.nkp;
+        for (int k = 0; k < EAGLE_N_LANDMARKS; ++k) { R->hm_idx[k] = 0; R->hm_score[k] = 0.f; }
+        write_bounds(R, S.H, Hok, pp.frame_h, pp.frame_w);
+    }
+    __syncthreads();
+    for (int k = tid; k < S.nkp; k += POST_T) R->kp[k] = S.kp[k];
+    project_detections(R, S.H, S.H_ok != 0, tid);
+}
+
+// operator form of calculate_optical_flow's filter stage
+struct FilterArgs { ClipView cv; ChainState* st; int hue_frame; };
+__global__ __launch_bounds__(POST_T) void flow_filter_kernel(FilterArgs a)
+{
+    __shared__ FlowShared F;
+    const uint8_t* frame = a.cv.bgr + (size_t)a.hue_frame * a.cv.h * a.cv.w * 3;
+    flow_filter_block(F, a.st, frame, a.cv.h, a.cv.w, threadIdx.x);
+    if (threadIdx.x == 0) {
+        a.st->flow_n = F.nflow;
+        for (int k = 0; k < F.nflow; ++k) { EagleFlowKp e; e.label = F.flow[k].label; e.x = F.flow[k].x; e.y = F.flow[k].y; e.score = 0.f; a.st->flow[k] = e; }
+    }
+}
+
+// heat-map maxima -> mem[] entries (the up-front batch of cm.py:217-276 and on-demand detections)
+struct DecodeArgs { const ArgmaxPart* parts; PostParams pp; MemList* mem; int first, stride; };
+__global__ __launch_bounds__(64) void decode_mem_kernel(DecodeArgs a)
+{
+    __shared__ int hm_idx[64]; __shared__ float hm_score[64];
+    __shared__ EagleKeypoint kp[EAGLE_N_LANDMARKS];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    float best = -1.f; int bi = 0;
+    for (int c = 0; c < a.pp.hm_chunks; ++c) {
+        const ArgmaxPart p = a.parts[((size_t)f * a.pp.hm_chunks + c) * 64 + tid];
+        if (p.score > best) { best = p.score; bi = p.idx; }
+    }
+    hm_idx[tid] = bi; hm_score[tid] = best;
+    __syncthreads();
+    if (tid == 0) {
+        const int n = decode_dedup(hm_idx, hm_score, a.pp, kp);
+        MemList& M = a.mem[a.first + f * a.stride];
+        M.n = n;
+        for (int k = 0; k < n; ++k) { EagleFlowKp e; e.label = kp[k].label; e.x = kp[k].x; e.y = kp[k].y; e.score = kp[k].score; M.kp[k] = e; }
     }
 }
 
@@ -834,6 +1121,30 @@ void homography_only_launch(const float* d_img, const float* d_world, int npts, 
     static bool done = false;
     if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)homography_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HomoShared))); done = true; }
     hipLaunchKernelGGL(homography_kernel, dim3(1), dim3(POST_T), sizeof(HomoShared), s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void decode_mem_launch(const ArgmaxPart* parts, int n, const PostParams& pp, MemList* mem, int first, int stride, hipStream_t s)
+{
+    DecodeArgs a{parts, pp, mem, first, stride};
+    hipLaunchKernelGGL(decode_mem_kernel, dim3(n), dim3(64), 0, s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void chain_launch(const ClipView& cv, ChainState* st, const MemList* mem, EagleFrameResult* recs, const PostParams& pp, int frame,
+                  int kint, int hint, int calib, hipStream_t s)
+{
+    ChainArgs a{cv, st, mem, recs, pp, ransac_rng_table(), frame, kint, hint, calib};
+    static bool done = false;
+    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainShared))); done = true; }
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(POST_T), sizeof(ChainShared), s, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+void flow_filter_launch(const ClipView& cv, ChainState* st, int hue_frame, hipStream_t s)
+{
+    FilterArgs a{cv, st, hue_frame};
+    hipLaunchKernelGGL(flow_filter_kernel, dim3(1), dim3(POST_T), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include <cstddef>
 #include "common.h"
 
 namespace eagle {
@@ -111,6 +112,17 @@ struct EagleHandle {
     std::vector<hipEvent_t> conv_ev;
     EagleTimings timings{};
     double conv_flop_step = 0; int n_conv = 0, n_launch = 0;
+    // clip session of the optical-flow cadence (eagle_clip_*)
+    struct Clip {
+        bool open = false;
+        ClipView cv;
+        uint8_t* g[3] = {nullptr, nullptr, nullptr};
+        EagleFrameResult* recs = nullptr;
+        MemList* mem = nullptr;
+        ChainState* st = nullptr;          // loop state
+        ChainState* st_op = nullptr;       // scratch state of eagle_clip_flow
+        ChainState* h_st = nullptr;        // pinned staging
+    } clip;
     // comm
     void* rccl = nullptr; void* comm = nullptr; int rank = 0, world = 1;
 };
@@ -569,6 +581,101 @@ static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage sta
     h->timings.total_ms = ms;
 }
 
+// ---- clip session (optical-flow cadence) ----------------------------------------------------------------------------------
+static void clip_close(EagleHandle* h)
+{
+    EagleHandle::Clip& c = h->clip;
+    for (auto& p : c.g) { if (p) (void)hipFree(p); p = nullptr; }
+    if (c.recs) (void)hipFree(c.recs);
+    if (c.mem) (void)hipFree(c.mem);
+    if (c.st) (void)hipFree(c.st);
+    if (c.st_op) (void)hipFree(c.st_op);
+    if (c.h_st) (void)hipHostFree(c.h_st);
+    c = EagleHandle::Clip();
+}
+
+static void clip_reset_state(EagleHandle* h, ChainState* d)
+{
+    ChainState& z = *h->clip.h_st;
+    memset(&z, 0, sizeof(z));
+    z.stalled = -1;
+    HIP_CHECK(hipMemcpyAsync(d, &z, sizeof(z), hipMemcpyHostToDevice, h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+}
+
+// detector + decode + NMS + object rules of every frame (cm.py:331 detect_objects), records kept in HBM
+static void clip_open(EagleHandle* h, const uint8_t* d_bgr, int n)
+{
+    clip_close(h);
+    const EagleConfig& cf = h->cfg;
+    EagleHandle::Clip& c = h->clip;
+    c.cv.bgr = d_bgr; c.cv.n = n; c.cv.h = cf.frame_h; c.cv.w = cf.frame_w;
+    c.cv.lh[0] = cf.frame_h; c.cv.lw[0] = cf.frame_w; c.cv.levels = 0;
+    for (int l = 1; l <= 2; ++l) {                       // cv2 maxLevel = 2 (cm.py:65); a level must exceed the 15x15 window
+        c.cv.lh[l] = (c.cv.lh[l - 1] + 1) / 2; c.cv.lw[l] = (c.cv.lw[l - 1] + 1) / 2;
+        if (c.cv.lw[l] <= 15 || c.cv.lh[l] <= 15) break;
+        c.cv.levels = l;
+    }
+    for (int l = 0; l < 3; ++l) {
+        HIP_CHECK(hipMalloc((void**)&c.g[l], std::max<size_t>((size_t)n * c.cv.lh[l] * c.cv.lw[l], 16)));
+        c.cv.g[l] = c.g[l];
+    }
+    HIP_CHECK(hipMalloc((void**)&c.recs, sizeof(EagleFrameResult) * (size_t)std::max(n, 1)));
+    HIP_CHECK(hipMalloc((void**)&c.mem, sizeof(MemList) * (size_t)std::max(n, 1)));
+    HIP_CHECK(hipMalloc((void**)&c.st, sizeof(ChainState)));
+    HIP_CHECK(hipMalloc((void**)&c.st_op, sizeof(ChainState)));
+    HIP_CHECK(hipHostMalloc((void**)&c.h_st, sizeof(ChainState), hipHostMallocDefault));
+    c.open = true;
+    HIP_CHECK(hipMemsetAsync(c.mem, 0xFF, sizeof(MemList) * (size_t)std::max(n, 1), h->s_main));      // n = -1 everywhere
+    clip_reset_state(h, c.st);
+    if (n == 0) return;
+    gray_pyramid_launch(d_bgr, n, c.cv.h, c.cv.w, c.g[0], c.g[1], c.g[2], h->s_main);
+    const int B = cf.batch;
+    const size_t fb = (size_t)cf.frame_h * cf.frame_w * 3;
+    size_t ev_i = 0;
+    EagleHandle::StepBuf& sb = h->sb[0];
+    const bool prof = h->prof; h->prof = false;
+    for (int i = 0; i < n; i += B) {
+        const int na = std::min(B, n - i);
+        HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
+        preprocess_launch(h->prec, d_bgr + (size_t)i * fb, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
+        run_net(h, h->yo.get(), h->s_main, ev_i);
+        yolo_decode_launch(h->levels, 3, B, 5, cf.detector_floor, h->ds, h->s_main);
+        nms_launch(h->ds, B, h->pp, sb.d_out, h->s_main);
+        HIP_CHECK(hipMemcpyAsync(c.recs + i, sb.d_out, sizeof(EagleFrameResult) * na, hipMemcpyDeviceToDevice, h->s_main));
+    }
+    h->prof = prof;
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+}
+
+// HRNet + heat-map maxima + decode of frames first, first+stride, ... -> mem[]
+static void clip_detect_keypoints(EagleHandle* h, int first, int stride, int count)
+{
+    const EagleConfig& cf = h->cfg;
+    EagleHandle::Clip& c = h->clip;
+    const int B = cf.batch;
+    const size_t fb = (size_t)cf.frame_h * cf.frame_w * 3;
+    size_t ev_i = 0;
+    EagleHandle::StepBuf& sb = h->sb[0];
+    const bool prof = h->prof; h->prof = false;
+    for (int k0 = 0; k0 < count; k0 += B) {
+        const int na = std::min(B, count - k0);
+        const uint8_t* src;
+        if (stride == 1) src = c.cv.bgr + (size_t)(first + k0) * fb;
+        else {
+            for (int k = 0; k < na; ++k)
+                HIP_CHECK(hipMemcpyAsync(sb.d_frames + (size_t)k * fb, c.cv.bgr + (size_t)(first + (k0 + k) * stride) * fb, fb, hipMemcpyDeviceToDevice, h->s_main));
+            src = sb.d_frames;
+        }
+        preprocess_launch(h->prec, src, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
+        run_net(h, h->hr.get(), h->s_main, ev_i);
+        heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
+        decode_mem_launch(sb.parts, na, h->pp, c.mem, first + k0 * stride, stride, h->s_main);
+    }
+    h->prof = prof;
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+}
+
 static void finalize(EagleHandle* h)
 {
     const EagleConfig& c = h->cfg;
@@ -682,6 +789,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
 
 void eagle_destroy(EagleHandle* h)
 {
+    if (h && h->clip.open) { (void)hipSetDevice(h->cfg.device); eagle::clip_close(h); }
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
@@ -794,6 +902,120 @@ int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double*
     HIP_CHECK(hipMemcpyAsync(recs, d_r, sizeof(EagleFrameResult) * (size_t)n, hipMemcpyDeviceToHost, h->s_main));
     HIP_CHECK(hipStreamSynchronize(h->s_main));
     (void)hipFree(d_r); (void)hipFree(d_H); (void)hipFree(d_f);
+    API_END(h)
+}
+
+#define CLIP_CHECK(h, cond, msg) if (!(h) || !(h)->finalized) return EAGLE_E_STATE; if (!(cond)) { (h)->err = msg; return EAGLE_E_INVALID; }
+int eagle_clip_open(EagleHandle* h, const void* d_bgr, int n)
+{
+    CLIP_CHECK(h, n >= 0 && (d_bgr || n == 0), "eagle_clip_open: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    eagle::clip_open(h, (const uint8_t*)d_bgr, n);
+    API_END(h)
+}
+
+int eagle_clip_close(EagleHandle* h)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    eagle::clip_close(h);
+    API_END(h)
+}
+
+int eagle_clip_detect_keypoints(EagleHandle* h, int first, int stride, int count)
+{
+    CLIP_CHECK(h, h->clip.open && first >= 0 && stride >= 1 && count >= 0 && (count == 0 || first + (int64_t)(count - 1) * stride < h->clip.cv.n),
+               "eagle_clip_detect_keypoints: no open clip or frames out of range")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    eagle::clip_detect_keypoints(h, first, stride, count);
+    API_END(h)
+}
+
+int eagle_clip_get_keypoints(EagleHandle* h, int frame, EagleFlowKp* out, int* n)
+{
+    CLIP_CHECK(h, h->clip.open && frame >= 0 && frame < h->clip.cv.n && out && n, "eagle_clip_get_keypoints: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    MemList m;
+    HIP_CHECK(hipMemcpy(&m, h->clip.mem + frame, sizeof(m), hipMemcpyDeviceToHost));
+    *n = m.n;
+    for (int k = 0; k < m.n && k < EAGLE_N_LANDMARKS; ++k) out[k] = m.kp[k];
+    API_END(h)
+}
+
+int eagle_clip_set_keypoints(EagleHandle* h, int frame, const EagleFlowKp* in, int n)
+{
+    CLIP_CHECK(h, h->clip.open && frame >= 0 && frame < h->clip.cv.n && n >= -1 && n <= EAGLE_N_LANDMARKS && (in || n <= 0),
+               "eagle_clip_set_keypoints: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    MemList m; memset(&m, 0, sizeof(m));
+    m.n = n;
+    for (int k = 0; k < n; ++k) m.kp[k] = in[k];
+    HIP_CHECK(hipMemcpy(h->clip.mem + frame, &m, sizeof(m), hipMemcpyHostToDevice));
+    API_END(h)
+}
+
+int eagle_clip_flow(EagleHandle* h, int src_frame, int dst_frame, int hue_frame, const EagleFlowKp* in, int n_in,
+                    EagleFlowKp* out, int* n_out, float* next_pts, uint8_t* status)
+{
+    CLIP_CHECK(h, h->clip.open && src_frame >= 0 && src_frame < h->clip.cv.n && dst_frame >= 0 && dst_frame < h->clip.cv.n && hue_frame >= 0 &&
+               hue_frame < h->clip.cv.n && n_in >= 0 && n_in <= EAGLE_N_LANDMARKS && (in || n_in == 0) && out && n_out,
+               "eagle_clip_flow: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    EagleHandle::Clip& c = h->clip;
+    *n_out = 0;
+    if (n_in == 0) return EAGLE_OK;                       // cm.py:429: empty dict in -> empty dict out
+    ChainState& z = *c.h_st;
+    memset(&z, 0, sizeof(z));
+    z.stalled = -1; z.n_prev = n_in;
+    for (int k = 0; k < n_in; ++k) z.prev[k] = in[k];
+    HIP_CHECK(hipMemcpyAsync(c.st_op, &z, sizeof(z), hipMemcpyHostToDevice, h->s_main));
+    lk_launch(c.cv, src_frame, dst_frame, c.st_op, nullptr, 1, h->s_main);
+    flow_filter_launch(c.cv, c.st_op, hue_frame, h->s_main);
+    HIP_CHECK(hipMemcpyAsync(&z, c.st_op, sizeof(z), hipMemcpyDeviceToHost, h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    *n_out = z.flow_n;
+    for (int k = 0; k < z.flow_n; ++k) out[k] = z.flow[k];
+    if (next_pts) memcpy(next_pts, z.lk_next, sizeof(float) * 2 * n_in);
+    if (status) memcpy(status, z.lk_status, n_in);
+    API_END(h)
+}
+
+int eagle_clip_run(EagleHandle* h, int first, int keypoint_interval, int homography_interval, int calibration, int* stalled_at)
+{
+    CLIP_CHECK(h, h->clip.open && first >= 0 && first <= h->clip.cv.n && keypoint_interval >= 1 && homography_interval >= 1 && stalled_at,
+               "eagle_clip_run: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    EagleHandle::Clip& c = h->clip;
+    if (first == 0) eagle::clip_reset_state(h, c.st);
+    else {                                                // resume after an on-demand detection
+        int clear = -1;
+        HIP_CHECK(hipMemcpyAsync((char*)c.st + offsetof(ChainState, stalled), &clear, sizeof(int), hipMemcpyHostToDevice, h->s_main));
+    }
+    for (int i = first; i < c.cv.n; ++i) {
+        lk_launch(c.cv, i > 0 ? i - 1 : 0, i, c.st, c.mem, keypoint_interval, h->s_main);
+        chain_launch(c.cv, c.st, c.mem, c.recs, h->pp, i, keypoint_interval, homography_interval, calibration, h->s_main);
+    }
+    int tail[2] = {-1, 0};
+    HIP_CHECK(hipMemcpyAsync(tail, (char*)c.st + offsetof(ChainState, stalled), sizeof(tail), hipMemcpyDeviceToHost, h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    *stalled_at = tail[0];
+    if (tail[1]) { h->err = "the reference raises IndexError in calibrate_keypoints at frame " + std::to_string(tail[1] - 1); return EAGLE_E_REFERENCE_RAISES; }
+    API_END(h)
+}
+
+int eagle_clip_fetch(EagleHandle* h, EagleFrameResult* out)
+{
+    CLIP_CHECK(h, h->clip.open && (out || h->clip.cv.n == 0), "eagle_clip_fetch: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    if (h->clip.cv.n > 0) HIP_CHECK(hipMemcpy(out, h->clip.recs, sizeof(EagleFrameResult) * (size_t)h->clip.cv.n, hipMemcpyDeviceToHost));
     API_END(h)
 }
 

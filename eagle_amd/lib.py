@@ -75,6 +75,14 @@ def load():
     L.eagle_device_free.argtypes = [vp, vp]
     L.eagle_device_upload.argtypes = [vp, vp, vp, i64]
     L.eagle_reproject.argtypes = [vp, vp, i32, dp, u8p]
+    L.eagle_clip_open.argtypes = [vp, vp, i32]
+    L.eagle_clip_close.argtypes = [vp]
+    L.eagle_clip_detect_keypoints.argtypes = [vp, i32, i32, i32]
+    L.eagle_clip_get_keypoints.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.eagle_clip_set_keypoints.argtypes = [vp, i32, vp, i32]
+    L.eagle_clip_flow.argtypes = [vp, i32, i32, i32, vp, i32, vp, C.POINTER(i32), fp, u8p]
+    L.eagle_clip_run.argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32)]
+    L.eagle_clip_fetch.argtypes = [vp, vp]
     L.eagle_comm_id.argtypes = [vp]
     L.eagle_comm_init.argtypes = [vp, i32, i32, vp]
     L.eagle_gather.argtypes = [vp, vp, i32, vp]
@@ -92,7 +100,11 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_finalize_weights", "eagle_process_frames", "eagle_process_device_frames", "eagle_device_alloc",
            "eagle_device_free", "eagle_device_upload", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
-           "eagle_op_find_homography"]
+           "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
+           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch"]
+
+FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
+E_REFERENCE_RAISES = -7
 
 
 def abi_sizes():
@@ -188,6 +200,49 @@ class Handle:
         self._check(self.L.eagle_reproject(self._h, recs.ctypes.data_as(C.c_void_p), len(recs), Hs.ctypes.data_as(C.POINTER(C.c_double)),
                                            flags.ctypes.data_as(C.POINTER(C.c_uint8))), "reproject")
         return recs
+
+    # --- clip session: optical-flow key-point cadence (include/eagle.h, eagle_clip_*) --------------------
+    def clip_open(self, dptr, n):
+        self._check(self.L.eagle_clip_open(self._h, dptr, n), "clip_open")
+
+    def clip_close(self):
+        self._check(self.L.eagle_clip_close(self._h), "clip_close")
+
+    def clip_detect_keypoints(self, first, stride=1, count=1):
+        self._check(self.L.eagle_clip_detect_keypoints(self._h, first, stride, count), "clip_detect_keypoints")
+
+    def clip_get_keypoints(self, frame):
+        """mem[frame] as a FLOWKP_DTYPE array in dict order, or None when the frame has no entry."""
+        buf = np.zeros(N_LANDMARKS, FLOWKP_DTYPE); n = C.c_int(0)
+        self._check(self.L.eagle_clip_get_keypoints(self._h, frame, buf.ctypes.data_as(C.c_void_p), C.byref(n)), "clip_get_keypoints")
+        return None if n.value < 0 else buf[: n.value].copy()
+
+    def clip_set_keypoints(self, frame, kps):
+        kps = np.ascontiguousarray(kps, FLOWKP_DTYPE)
+        self._check(self.L.eagle_clip_set_keypoints(self._h, frame, kps.ctypes.data_as(C.c_void_p), len(kps)), "clip_set_keypoints")
+
+    def clip_flow(self, src_frame, dst_frame, hue_frame, kps, raw=False):
+        """calculate_optical_flow (cm.py:419-478) on resident frames -> filtered FLOWKP_DTYPE array (+ raw LK output)."""
+        kps = np.ascontiguousarray(kps, FLOWKP_DTYPE)
+        out = np.zeros(N_LANDMARKS, FLOWKP_DTYPE); n = C.c_int(0)
+        nxt = np.zeros((max(len(kps), 1), 2), np.float32); st = np.zeros(max(len(kps), 1), np.uint8)
+        self._check(self.L.eagle_clip_flow(self._h, src_frame, dst_frame, hue_frame, kps.ctypes.data_as(C.c_void_p), len(kps),
+                                           out.ctypes.data_as(C.c_void_p), C.byref(n), _fp(nxt), st.ctypes.data_as(C.POINTER(C.c_uint8))), "clip_flow")
+        return (out[: n.value].copy(), nxt[: len(kps)], st[: len(kps)]) if raw else out[: n.value].copy()
+
+    def clip_run(self, first, keypoint_interval, homography_interval, calibration=False):
+        """Runs the loop body for frames first.. on the GPU; -> index of a frame that needs an on-demand detection, or -1."""
+        stalled = C.c_int(-1)
+        rc = self.L.eagle_clip_run(self._h, first, keypoint_interval, homography_interval, int(calibration), C.byref(stalled))
+        if rc == E_REFERENCE_RAISES:
+            raise IndexError(self.L.eagle_last_error(self._h).decode())
+        self._check(rc, "clip_run")
+        return stalled.value
+
+    def clip_fetch(self, n):
+        out = np.zeros(n, RESULT_DTYPE)
+        self._check(self.L.eagle_clip_fetch(self._h, out.ctypes.data_as(C.c_void_p)), "clip_fetch")
+        return out
 
     def set_profiling(self, on):
         self._check(self.L.eagle_set_profiling(self._h, int(on)), "set_profiling")

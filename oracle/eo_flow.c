@@ -94,6 +94,8 @@ static inline void scharr(const Img* im, int y, int x, int* dx, int* dy)
 }
 #define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 #define WIN 15
+/* coordinates beyond any image (float -> int conversion of such values is unspecified in C and saturating on the GPU) count as outside */
+#define FAR(x, y) (!(fabsf(x) < 1e8f && fabsf(y) < 1e8f))
 #define W_BITS 14
 
 /* prev_pts/next_pts: n x 2 float32; status: n bytes.  flags = 0, minEigThreshold = 1e-4, err requested (the Python binding always does). */
@@ -131,7 +133,7 @@ void eo_calc_optical_flow_pyr_lk(const uint8_t* prev_gray, const uint8_t* next_g
             next_pts[2 * pt] = nx; next_pts[2 * pt + 1] = ny;
             ppx -= half; ppy -= half;
             const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
-            if (ipx < -WIN || ipx >= Il->w || ipy < -WIN || ipy >= Il->h) {
+            if (FAR(ppx, ppy) || ipx < -WIN || ipx >= Il->w || ipy < -WIN || ipy >= Il->h) {
                 if (level == 0) status[pt] = 0;
                 continue;
             }
@@ -166,7 +168,7 @@ void eo_calc_optical_flow_pyr_lk(const uint8_t* prev_gray, const uint8_t* next_g
             float pdx = 0.f, pdy = 0.f;
             for (int j = 0; j < max_count; ++j) {
                 const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-                if (inx < -WIN || inx >= Jl->w || iny < -WIN || iny >= Jl->h) {
+                if (FAR(nx, ny) || inx < -WIN || inx >= Jl->w || iny < -WIN || iny >= Jl->h) {
                     if (level == 0) status[pt] = 0;
                     break;
                 }
@@ -196,7 +198,7 @@ void eo_calc_optical_flow_pyr_lk(const uint8_t* prev_gray, const uint8_t* next_g
             if (status[pt] && level == 0) {               /* the err branch: the final window must start inside J's frame */
                 const float fx = next_pts[2 * pt] - half, fy = next_pts[2 * pt + 1] - half;
                 const int rx = (int)lrintf(fx), ry = (int)lrintf(fy);
-                if (rx < -WIN || rx >= Jl->w || ry < -WIN || ry >= Jl->h) status[pt] = 0;
+                if (FAR(fx, fy) || rx < -WIN || rx >= Jl->w || ry < -WIN || ry >= Jl->h) status[pt] = 0;
             }
         }
     }

@@ -1,0 +1,153 @@
+"""Optical-flow key-point cadence on the GPU (eagle_clip_* of include/eagle.h).
+
+1. the LK tracker + filters (K12, flow_filter) against oracle/eo_flow.c + oracle/flow.py: new points, status and the filtered
+   dict BIT-EXACT (all-integer window arithmetic; the float ops are written in the same order on both sides);
+2. the whole loop against the records the REFERENCE's own loop produced (tests/golden/flow_golden.json) when the same canned
+   key-point detections are replayed: "Keypoints" (values, order, int/float type), "Boundaries", and which frames were detected;
+3. the whole loop with the real networks (fp32 family) against the oracle's loop restatement fed with the per-frame detections
+   of the stateless path (themselves proven identical to the oracle by test_gpu_pipeline.py): full records."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import flow_cases
+from eagle_amd import lib, records, weights
+from eagle_amd.coordinate_model import CoordinateModel
+from eagle_amd.pitch import INTERSECTION_TO_PITCH_POINTS, PITCH_POINTS_TO_INTERSECTION
+from oracle import flow, host
+from oracle import prims as P
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "flow_golden.json")))
+
+
+def _norm(o):
+    return json.loads(json.dumps(o, default=lambda v: v.tolist() if isinstance(v, np.ndarray) else (int(v) if isinstance(v, np.integer) else float(v))))
+
+
+def to_flowkp(d, scores=None):
+    a = np.zeros(len(d), lib.FLOWKP_DTYPE)
+    for k, (lab, (x, y)) in enumerate(d.items()):
+        a[k] = (PITCH_POINTS_TO_INTERSECTION[lab], int(x), int(y), 0.0 if scores is None else scores.get(lab, 0.0))
+    return a
+
+
+def from_flowkp(a):
+    return {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"])) for k in a}
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = CoordinateModel(precision="f16", batch=8)
+    yield m
+    m.handle.close()
+
+
+def test_lk_and_filters_bit_exact(model):
+    h = model.handle
+    frames = np.stack(flow_cases.frames_of("fps25")[:6] + flow_cases.frames_of("blackout")[1:4])
+    n = len(frames)
+    d = h.upload(frames)
+    try:
+        h.clip_open(d, n)
+        gray = [P.bgr2gray(f) for f in frames]
+        rng = np.random.default_rng(3)
+        cases = 0
+        for (a, b) in [(0, 1), (1, 2), (4, 5), (5, 4), (0, 5), (6, 7), (7, 8), (2, 2)]:
+            kps = {INTERSECTION_TO_PITCH_POINTS[i]: (int(x), int(y)) for i, (x, y) in
+                   zip(rng.permutation(57)[:40], np.stack([rng.integers(-20, 1300, 40), rng.integers(-20, 740, 40)], 1))}
+            # a few points on real landmarks, a few on the frame border, a few far outside
+            vis = list(flow_cases.synth.visible_landmarks(2, 60 + 4 * a).items())[:12]
+            for i, (x, y) in vis:
+                kps[INTERSECTION_TO_PITCH_POINTS[i]] = (x, y)
+            got, nxt, st = h.clip_flow(a, b, b, to_flowkp(kps), raw=True)
+            pts = np.array(list(kps.values()), np.float32)
+            enxt, est = P.calc_optical_flow_pyr_lk(gray[a], gray[b], pts)
+            assert np.array_equal(st, est[:, 0]), (a, b)
+            assert np.array_equal(nxt[st == 1].view(np.uint32), enxt[est[:, 0] == 1].view(np.uint32)), (a, b, "LK points differ")
+            exp = flow.calculate_optical_flow(frames[b], gray[a], kps, gray[b])
+            assert from_flowkp(got) == {k: (int(v[0]), int(v[1])) for k, v in exp.items()} and list(from_flowkp(got)) == list(exp), (a, b)
+            cases += len(pts)
+        assert cases > 300
+    finally:
+        h.clip_close(); h.free(d)
+
+
+@pytest.mark.parametrize("name", sorted(flow_cases.CLIPS))
+def test_loop_with_replayed_detections_equals_reference_loop(model, name):
+    fps, nh, nk, spec, calib = flow_cases.CLIPS[name]
+    frames = np.stack(flow_cases.frames_of(name))
+    kps, _ = flow_cases.canned(name)
+    hgt, wid = frames[0].shape[:2]
+
+    def source(i):
+        dec = [t for t in kps[i] if t[3] > 0.01]
+        d = host.keypoints_from_decoded(dec, hgt, wid, 0.3)
+        return to_flowkp(d, {INTERSECTION_TO_PITCH_POINTS[t[0]]: t[3] for t in dec})
+
+    stats = {}
+    kint, hint = max(1, int(fps / max(1, nk))), max(1, int(fps / max(1, nh)))
+    gold = GOLD[name]
+    if gold["raises"]:
+        with pytest.raises(Exception) as e:
+            model.flow_records(frames, kint, hint, calib, keypoint_source=source)
+        assert type(e.value).__name__ == gold["raises"]
+        return
+    recs = model.flow_records(frames, kint, hint, calib, stats=stats, keypoint_source=source)
+    assert stats["detected_frames"] == gold["detected_frames"]
+    for i, r in enumerate(recs):
+        got = _norm(records.to_reference_dict(r, i, fps, own_h=bool(r["pad"][0])))
+        ref = gold["records"][str(i)]
+        assert got["Keypoints"] == ref["Keypoints"], (name, i)
+        assert list(got["Keypoints"]) == list(ref["Keypoints"]), (name, i, "dict order")
+        assert got["Boundaries"] == ref["Boundaries"] and got["Time"] == ref["Time"], (name, i)
+
+
+def test_loop_with_real_networks_equals_oracle_loop():
+    """fp32 family end to end: HRNet / YOLOv8 detections come from the stateless path, the oracle's loop restatement consumes
+    them, and the clip session (which runs the same networks itself, on the cadence's frames only) must agree record by record."""
+    hs, ys = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("n", 0)
+    m = CoordinateModel(precision="f32", batch=4, hrnet_state_dict=hs, detector_state_dict=ys, keypoint_conf=0.3)
+    try:
+        frames = np.stack(flow_cases.frames_of("pan")[:7])
+        base = m.process_records(frames)
+        hgt, wid = frames[0].shape[:2]
+
+        def det_kp(i):
+            return {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"]))
+                    for k in base[i]["kp"][: int(base[i]["n_kp"])] if not k["synthesized"]}
+
+        def det_obj(i):
+            r = base[i]
+            dets = np.stack([r["det"][k][: int(r["n_det"])] for k in ("x1", "y1", "x2", "y2", "conf")], 1)
+            dets = np.concatenate([dets, r["det"]["cls"][: int(r["n_det"])].astype(np.float32)[:, None]], 1)
+            return host.objects_from_detections(dets, hgt, wid, 0.35)
+
+        for (kint, hint) in [(3, 2), (2, 5)]:
+            stats = {}
+            recs = m.flow_records(frames, kint, hint, stats=stats)
+            exp, est = _oracle(frames, kint, hint, det_kp, det_obj)
+            assert stats["detected_frames"] == sorted(set(est["detect_calls"]))
+            for i, r in enumerate(recs):
+                got = _norm(records.to_reference_dict(r, i, 25, own_h=bool(r["pad"][0])))
+                ref = _norm(exp[i])
+                for cls in ref["Coordinates"].values():
+                    for o in cls.values():
+                        o.pop("_pitch_float", None)
+                assert got["Keypoints"] == ref["Keypoints"] and list(got["Keypoints"]) == list(ref["Keypoints"]), (kint, hint, i)
+                assert got["Coordinates"] == ref["Coordinates"], (kint, hint, i)
+                assert got["Boundaries"] == ref["Boundaries"], (kint, hint, i)
+    finally:
+        m.handle.close()
+
+
+def _oracle(frames, kint, hint, det_kp, det_obj):
+    # loop_records derives the intervals from fps: fps = lcm-free choice so that int(fps / num) gives exactly (kint, hint)
+    fps = kint * hint
+    res, st = flow.loop_records(frames, fps, fps // hint, fps // kint, det_kp, det_obj)
+    for i in res:
+        res[i]["Time"] = None
+    return res, st

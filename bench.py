@@ -73,10 +73,12 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--distinct", type=int, default=20, help="distinct synthetic frames generated (tiled to the clip)")
-    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the network phase as a hipGraph (no gain once a step is GPU-bound)")
     ap.add_argument("--host-frames", action="store_true", help="also time the PCIe-inclusive path (frames in pageable host memory, eagle_process_frames); reported as pcie_inclusive, never as value")
+    ap.add_argument("--cadence", type=int, default=0, metavar="FPS", help="also time the reference's default cadence on the same clip: get_coordinates(frames, FPS, num_homography=1, "
+                    "num_keypoint_detection=3) = HRNet every int(FPS/3)-th frame, optical-flow propagation in between (stateful; reported as reference_cadence, never as value)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --shared-gpu: dev test of the multi-rank path on one GPU)")
     ap.add_argument("--shared-gpu", action="store_true", help="every rank uses HIP device 0 (developer test only)")
@@ -168,6 +170,20 @@ def main():
         pcie = n_local / (time.perf_counter() - t1)
         log(f"PCIe-inclusive (pageable host frames): {pcie:.1f} frames/s")
 
+    cadence = None
+    if a.cadence > 0:
+        from eagle_amd import clip as clipmod
+        kint, hint = max(1, int(a.cadence / 3)), max(1, int(a.cadence / 1))
+        st = {}
+        clipmod.run_clip(h, d_clip, min(n_local, 2 * kint + 1), kint, hint, False, st)          # warm-up
+        t1 = time.perf_counter()
+        clipmod.run_clip(h, d_clip, n_local, kint, hint, False, st)
+        dtc = time.perf_counter() - t1
+        cadence = {"value": round(n_local / dtc, 2), "unit": "frames/s", "fps": a.cadence, "keypoint_interval": kint, "homography_interval": hint,
+                   "hrnet_frames": len(st["detected_frames"]), "frames": n_local,
+                   "note": "stateful reference cadence (cm.py:205-206): detector on every frame, HRNet on hrnet_frames of them, LK flow + loop body per frame; one clip, one GPU"}
+        log(f"reference cadence @{a.cadence} fps: {cadence['value']} frames/s ({cadence['hrnet_frames']} HRNet frames)")
+
     # dominant kernel = the implicit-GEMM convolution family: per-launch HIP events on the launch stream
     h.set_profiling(1)
     prof_steps = 2
@@ -196,7 +212,7 @@ def main():
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}",
                        "gather": "none" if world == 1 else gather_used, "hip_graph": bool(a.graph)},
-            "roofline": {"bound": "mfma", "kernel": "conv_f16_kernel / conv_f16_dma_kernel <KS,S,KC,NT> (all 356 convolution launches of a step)" if a.precision == "f16" else "conv_f32_kernel",
+            "roofline": {"bound": "mfma", "kernel": "conv_f16_kernel / conv_f16_ws_kernel (all 356 convolution launches of a step)" if a.precision == "f16" else "conv_f32_kernel",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3, "unit": "TFLOP/s",
                          "frac": round(achieved / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
                          "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
@@ -204,6 +220,8 @@ def main():
                          "algorithmic_bytes_note": "MFMA-bound kernel: achieved is FLOP-based; traffic = measured HBM bytes per conv launch (PMC)",
                          "traffic": traffic},
         }
+        if cadence is not None:
+            res["reference_cadence"] = cadence
         if pcie is not None:
             res["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s", "note": "frames in pageable host memory -> eagle_process_frames (H2D overlapped on a copy stream)"}
         if not a.no_cpu_baseline:

@@ -6,7 +6,8 @@ the GPU path and write ``raw_coordinates.json`` exactly the way the reference's 
     python -m eagle_amd.cli --clip frames.npy --fps 25 --out output/myclip       # uint8 [n,h,w,3] BGR frames
 
 Video decode/encode, the pandas post-processor and the annotated video of ``main.py:34-81`` are out of scope
-(SURVEY §8f rows 3-4).  The stateless cadence is used: key-points and homography on every frame."""
+(SURVEY §8f rows 3-4).  The cadence is main.py:27's by default (homography once per second, key-point model three times per
+second, optical flow in between); ``--every-frame`` selects the stateless configuration (both on every frame)."""
 import argparse
 import json
 import os
@@ -27,6 +28,10 @@ def main(argv=None):
     ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
     ap.add_argument("--batch", type=int, default=10)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--num-homography", type=int, default=1, help="homography solves per second (main.py:27: 1)")
+    ap.add_argument("--num-keypoint-detection", type=int, default=3, help="key-point model runs per second (main.py:27: 3)")
+    ap.add_argument("--every-frame", action="store_true", help="key-points and homography on every frame (stateless configuration)")
+    ap.add_argument("--calibration", action="store_true")
     a = ap.parse_args(argv)
 
     from . import synth
@@ -36,7 +41,8 @@ def main(argv=None):
     model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
                             precision=a.precision, device=a.device, seed=a.seed)
     t0 = time.perf_counter()
-    coordinates = model.get_coordinates(frames, a.fps, num_homography=a.fps, num_keypoint_detection=a.fps, verbose=False)
+    nh, nk = (a.fps, a.fps) if a.every_frame else (a.num_homography, a.num_keypoint_detection)
+    coordinates = model.get_coordinates(frames, a.fps, num_homography=nh, num_keypoint_detection=nk, verbose=False, calibration=a.calibration)
     dt = time.perf_counter() - t0
     os.makedirs(a.out, exist_ok=True)
     with open(os.path.join(a.out, "raw_coordinates.json"), "w") as f:

@@ -9,7 +9,7 @@ cm.py:188-416); tracker IDs (boxmot BotSort, cm.py:577) are the remaining SURVEY
 detection-index fallback (cm.py:598-627)."""
 import numpy as np
 
-from . import lib, records, weights
+from . import clip, lib, records, weights
 from .pitch import INTERSECTION_TO_PITCH_POINTS
 
 
@@ -65,78 +65,15 @@ class CoordinateModel:
         return {i: records.to_reference_dict(r, i, fps, own_h=bool(own[i])) for i, r in enumerate(recs)}
 
     def flow_records(self, frames, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None):
-        """The reference loop in a stateful cadence (cm.py:188-416), sequenced on the GPU by the clip session of the C ABI:
-        detector on every frame and HRNet on every keypoint_interval-th frame in batches, then one LK + one loop-body kernel
-        per frame without host round trips.  The host steps in only where the reference itself detects on demand.
-        keypoint_source(i) -> FLOWKP_DTYPE array: an external key-point detector replacing HRNet (what detect_keypoints(frames[i])
-        would return, in dict order); used by the parity tests to replay the reference's canned detections."""
-        h = self.handle
+        """Records of the reference loop in a stateful cadence (cm.py:188-416); see eagle_amd/clip.py."""
         frames = np.ascontiguousarray(frames, np.uint8)
-        n = len(frames)
-        if n == 0:
+        if len(frames) == 0:
             return np.zeros(0, lib.RESULT_DTYPE)
-        d = h.upload(frames)
-        detected = []
+        d = self.handle.upload(frames)
         try:
-            h.clip_open(d, n)
-            def detect(first, stride=1, count=1):
-                idx = [first + k * stride for k in range(count)]
-                if keypoint_source is None:
-                    h.clip_detect_keypoints(first, stride, count)
-                else:
-                    for i in idx:
-                        h.clip_set_keypoints(i, keypoint_source(i))
-                detected.extend(idx)
-
-            self._detect = detect
-            detect(0, keypoint_interval, (n + keypoint_interval - 1) // keypoint_interval)        # cm.py:217-276
-            m0 = h.clip_get_keypoints(0)
-            if len(m0) < 4 and n > 1:
-                self._first_frame_search(n, m0, detected)
-            first = 0
-            while True:
-                stalled = h.clip_run(first, keypoint_interval, homography_interval, calibration)
-                if stalled < 0:
-                    break
-                detect(stalled)                                                     # cm.py:317 on-demand detection
-                first = stalled
-            recs = h.clip_fetch(n)
+            return clip.run_clip(self.handle, d, len(frames), keypoint_interval, homography_interval, calibration, stats, keypoint_source)
         finally:
-            h.clip_close()
-            h.free(d)
-        if stats is not None:
-            stats["detected_frames"] = sorted(set(detected))
-        return recs
-
-    def _first_frame_search(self, n, m0, detected):
-        """cm.py:289-311: frame 0 detected fewer than 4 key-points -> find the first later frame with at least 4 and flow its
-        key-points back to frame 0 (the reference tracks from gray[j] to gray[j+1] with the points of frame j+1), merging
-        into mem[j] on the way.  Dict bookkeeping on the host; every flow runs on the GPU (eagle_clip_flow)."""
-        h = self.handle
-        prev, found = None, None
-        for j in range(1, n):
-            mj = h.clip_get_keypoints(j)
-            if mj is None:
-                self._detect(j)
-                mj = h.clip_get_keypoints(j)
-            if len(mj) >= 4:
-                prev, found = mj, j
-                break
-        if prev is None:
-            return
-        for j in range(found - 1, -1, -1):
-            flowed = h.clip_flow(j, j + 1, j, prev)
-            prev = flowed if len(flowed) > 0 else prev
-            old = h.clip_get_keypoints(j)
-            merged = {int(k["label"]): k for k in prev}                             # mem[j] = {**prev_keypoints, **mem.get(j, {})}
-            if old is not None:
-                for k in old:
-                    merged[int(k["label"])] = k
-            out = list(merged.values())
-            if j == 0:                                                              # cm.py:324 {**keypoints, **mem[0]}: the detected keys lead
-                lead = [int(k["label"]) for k in m0]
-                out = [merged[l] for l in lead] + [k for l, k in merged.items() if l not in lead]
-            h.clip_set_keypoints(j, np.array(out, lib.FLOWKP_DTYPE))
+            self.handle.free(d)
 
     def detect_objects(self, frame):
         rec = self.process_records(frame[None])[0]

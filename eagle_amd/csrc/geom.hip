@@ -899,7 +899,7 @@ __device__ bool calibrate_keypoints(EagleKeypoint* kp, int nkp, const uint8_t* f
             }
         int ax = x + bx - 3, ay = y + by - 3;
         ax = ax < 0 ? 0 : (ax > w - 1 ? w - 1 : ax); ay = ay < 0 ? 0 : (ay > h - 1 ? h - 1 : ay);
-        kp[k].x = ax; kp[k].y = ay;
+        kp[k].x = ax; kp[k].y = ay; kp[k].pad |= 2;          // value now is a numpy integer in the reference (np.clip)
     }
     return true;
 }

@@ -39,7 +39,10 @@ def to_reference_dict(rec, i=0, fps=25, own_h=True):
         keypoints = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: [float(k["x"]), float(k["y"])]
                      for k in kps if k["on_plane"] and k["inlier"]}
     else:
-        keypoints = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"])) for k in kps}
+        # values that came out of the optical flow (cm.py:476) or were moved by the calibration (cm.py:551-553) are numpy integers in
+        # the reference, and main.py's json.dump(default=float) writes those as floats: keep the type so the file is identical
+        keypoints = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: ((np.int64(k["x"]), np.int64(k["y"])) if k["pad"] else (int(k["x"]), int(k["y"])))
+                     for k in kps}
     if rec["bounds_valid"]:
         b = rec["bounds"]
         bounds = [(float(b[0]), 0), (float(b[1]), 68), (float(b[2]), 68), (float(b[3]), 0)]

@@ -146,7 +146,8 @@ int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double*
  *   eagle_clip_run              the loop body for frames first..n-1, in order, on the GPU without host round trips; stops early
  *                               at a frame that needs a model detection it does not have (*stalled_at = frame, else -1)
  *   eagle_clip_fetch            the n records.  EagleFrameResult.pad[0] = 1 when the frame solved its own homography
- *                               ("Keypoints" = its inliers, cm.py:359-362); kp[].pad = 1 for values that came from the flow. */
+ *                               ("Keypoints" = its inliers, cm.py:359-362); kp[].pad bit 0: the value came from the flow, bit 1: moved by the calibration
+ *                               (both are numpy integers in the reference's dict, which json.dump(default=float) writes as floats). */
 typedef struct EagleFlowKp { int32_t label; int32_t x, y; float score; } EagleFlowKp;
 int eagle_clip_open(EagleHandle* h, const void* d_bgr, int n);
 int eagle_clip_detect_keypoints(EagleHandle* h, int first, int stride, int count);

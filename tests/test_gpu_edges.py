@@ -156,3 +156,16 @@ def test_reference_cadence_homography_every_5th_frame(state_dicts):
         return float(d) if isinstance(d, (np.floating, float)) else (int(d) if isinstance(d, np.integer) else d)
     assert canon(got) == canon(ref)
     assert len(got) == 7 and all(set(v) == {"Coordinates", "Time", "Keypoints", "Boundaries"} for v in got.values())
+
+
+def test_cli_at_25_fps_uses_the_flow_cadence(tmp_path):
+    """main.py:27's call at 25 fps: HRNet on every 8th frame, optical flow in between, one homography per second; the file must
+    carry the reference's value types (flowed key-points are numpy integers there, which json.dump(default=float) writes as floats)."""
+    import json
+    from eagle_amd import cli
+    assert cli.main(["--frames", "11", "--fps", "25", "--out", str(tmp_path), "--batch", "4"]) == 0
+    d = json.load(open(tmp_path / "raw_coordinates.json"))
+    assert sorted(d, key=int) == [str(i) for i in range(11)]
+    assert all(set(r) == {"Coordinates", "Time", "Keypoints", "Boundaries"} for r in d.values())
+    every = cli.main(["--frames", "11", "--fps", "25", "--out", str(tmp_path / "e"), "--batch", "4", "--every-frame"])
+    assert every == 0 and len(json.load(open(tmp_path / "e" / "raw_coordinates.json"))) == 11

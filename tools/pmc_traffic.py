@@ -20,7 +20,7 @@ out = {"batch": 50, "detector": "n", "precision": "f16", "source": "rocprofv3 --
        "corrections": "bytes = KiB*1024; FETCH_SIZE doubled (gfx950 under-report of wide coalesced reads)", "kernels": {}}
 tf = tw = n = 0
 for k in fetch:
-    if "conv_f16_kernel" not in k and "conv_f32_kernel" not in k:
+    if "conv_f16" not in k and "conv_f32_kernel" not in k:
         continue
     c, v = fetch[k]
     w = write.get(k, [c, 0.0])[1]

@@ -549,8 +549,16 @@ __device__ bool intersect_lines(const double* l1, const double* l2, double* px, 
 }
 
 // ---- the per-frame kernel ---------------------------------------------------------------------------------------
+struct SynthShared {
+    double lines[2][PT_NY][4];                           // [0]: lines of constant world y, [1]: of constant world x
+    int lok[2][PT_NY];
+    int cx[PT_NY * PT_NX], cy[PT_NY * PT_NX];
+    unsigned char cok[PT_NY * PT_NX];
+    signed char slot_of[64];
+};
 struct PostShared {
     HomoShared hs;
+    SynthShared syn;
     int hm_idx[64]; float hm_score[64];
     EagleKeypoint kp[EAGLE_MAX_KP];
     int nkp;
@@ -618,48 +626,63 @@ __device__ int decode_dedup(const int* hm_idx, const float* hm_score, const Post
     return nkp;
 }
 
-// (3) synthesis by line intersection (cm.py:140-186); appends to kp[0..nkp) and returns the new count
-__device__ int synthesize_keypoints(EagleKeypoint* kp, int nkp)
+// (3) synthesis by line intersection (cm.py:140-186), workgroup-cooperative: the 38 line fits and the 361 candidate
+// intersections are independent and run one per thread; thread 0 then walks the candidates in the reference's order (y-lines
+// outer, x-lines inner, at most 30 additions) so the result is the serial one.  All threads call; appends to kp[0..*nkp).
+__device__ void synthesize_block(SynthShared& Y, EagleKeypoint* kp, int* nkp_io, int tid)
 {
-    signed char slot_of[57];
-    for (int i = 0; i < 57; ++i) slot_of[i] = -1;
-    for (int k = 0; k < nkp; ++k) slot_of[kp[k].label] = (signed char)k;
     static_assert(PT_NY == PT_NX, "one table shape for both line families");
-    double lines[2][PT_NY][4];                           // [0]: lines of constant world y, [1]: of constant world x
-    int lok[2][PT_NY];
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int g = 0; g < PT_NY; ++g) {
-            float pts[2 * PT_MAXG]; int np = 0;
-            for (int m = 0; m < PT_MAXG; ++m) {
-                const int lab = pass == 0 ? PT_YGROUP[g][m] : PT_XGROUP[g][m];
-                if (lab < 0) break;
-                if (PT_NOT_ON_PLANE_IDX[lab]) continue;
-                const int sl = slot_of[lab];
-                if (sl < 0) continue;
-                pts[2 * np] = (float)kp[sl].x; pts[2 * np + 1] = (float)kp[sl].y; ++np;
-            }
-            double line[4] = {0, 0, 0, 0};
-            lok[pass][g] = (np >= 2 && fit_line(pts, np, line)) ? 1 : 0;
-            for (int k = 0; k < 4; ++k) lines[pass][g][k] = line[k];
+    __syncthreads();                                     // *nkp_io and kp[] were written by thread 0
+    const int nkp0 = *nkp_io;
+    if (nkp0 < 2) return;                                // cm.py:326 (uniform: nkp lives in shared memory)
+    if (tid < 64) Y.slot_of[tid] = -1;
+    __syncthreads();
+    if (tid < nkp0) Y.slot_of[kp[tid].label] = (signed char)tid;          // labels are unique within a dict
+    __syncthreads();
+    if (tid < 2 * PT_NY) {
+        const int pass = tid / PT_NY, g = tid - pass * PT_NY;
+        float pts[2 * PT_MAXG]; int np = 0;
+        for (int m = 0; m < PT_MAXG; ++m) {
+            const int lab = pass == 0 ? PT_YGROUP[g][m] : PT_XGROUP[g][m];
+            if (lab < 0) break;
+            if (PT_NOT_ON_PLANE_IDX[lab]) continue;
+            const int sl = Y.slot_of[lab];
+            if (sl < 0) continue;
+            pts[2 * np] = (float)kp[sl].x; pts[2 * np + 1] = (float)kp[sl].y; ++np;
         }
+        double line[4] = {0, 0, 0, 0};
+        Y.lok[pass][g] = (np >= 2 && fit_line(pts, np, line)) ? 1 : 0;
+        for (int k = 0; k < 4; ++k) Y.lines[pass][g][k] = line[k];
     }
-    int added = 0;
-    for (int gy = 0; gy < PT_NY && added < 30; ++gy) {
-        if (!lok[0][gy]) continue;
-        for (int gx = 0; gx < PT_NX; ++gx) {
-            if (!lok[1][gx]) continue;
+    __syncthreads();
+    for (int c = tid; c < PT_NY * PT_NX; c += POST_T) {
+        const int gy = c / PT_NX, gx = c - gy * PT_NX;
+        unsigned char ok = 0;
+        if (Y.lok[0][gy] && Y.lok[1][gx]) {
             const int lab = PT_CROSS[gy][gx];
-            if (lab < 0 || slot_of[lab] >= 0) continue;
             double px, py;
-            if (!intersect_lines(lines[0][gy], lines[1][gx], &px, &py)) continue;
-            EagleKeypoint e; e.label = lab; e.x = (int)rint(px); e.y = (int)rint(py); e.score = 0.f;
-            e.synthesized = 1; e.on_plane = 0; e.inlier = 0; e.pad = 0;
-            slot_of[lab] = (signed char)nkp;
-            kp[nkp++] = e;
-            if (++added >= 30) break;
+            if (lab >= 0 && Y.slot_of[lab] < 0 && intersect_lines(Y.lines[0][gy], Y.lines[1][gx], &px, &py)) {
+                ok = 1; Y.cx[c] = (int)rint(px); Y.cy[c] = (int)rint(py);
+            }
         }
+        Y.cok[c] = ok;
     }
-    return nkp;
+    __syncthreads();
+    if (tid == 0) {
+        int nkp = nkp0, added = 0;
+        for (int c = 0; c < PT_NY * PT_NX && added < 30; ++c) {
+            if (!Y.cok[c]) continue;
+            const int lab = PT_CROSS[c / PT_NX][c % PT_NX];
+            if (Y.slot_of[lab] >= 0) continue;
+            EagleKeypoint e; e.label = lab; e.x = Y.cx[c]; e.y = Y.cy[c]; e.score = 0.f;
+            e.synthesized = 1; e.on_plane = 0; e.inlier = 0; e.pad = 0;
+            Y.slot_of[lab] = (signed char)nkp;
+            kp[nkp++] = e;
+            ++added;
+        }
+        *nkp_io = nkp;
+    }
+    __syncthreads();
 }
 
 // (4) on-plane selection (cm.py:338-349): float32 image and world points
@@ -735,12 +758,9 @@ __global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
     }
     __syncthreads();
 
-    if (tid == 0) {
-        int nkp = decode_dedup(S.hm_idx, S.hm_score, pp, S.kp);
-        if (nkp >= 2) nkp = synthesize_keypoints(S.kp, nkp);          // cm.py:326
-        S.nkp = nkp;
-        S.npts = select_plane_points(S.kp, nkp, S.img, S.world, S.used);
-    }
+    if (tid == 0) S.nkp = decode_dedup(S.hm_idx, S.hm_score, pp, S.kp);
+    synthesize_block(S.syn, S.kp, &S.nkp, tid);                       // cm.py:326 (barriers inside)
+    if (tid == 0) S.npts = select_plane_points(S.kp, S.nkp, S.img, S.world, S.used);
     __syncthreads();
 
     // (5) homography
@@ -809,6 +829,7 @@ __device__ float np_sum_f32(const float* a, int n)
 }
 
 struct FlowShared {
+    float nxt[2 * EAGLE_N_LANDMARKS], prv[2 * EAGLE_N_LANDMARKS]; int lab[EAGLE_N_LANDMARKS]; unsigned char status[EAGLE_N_LANDMARKS];
     double hue[2 * EAGLE_N_LANDMARKS];     // [2*p] around the new point, [2*p+1] around the previous point
     float move[EAGLE_N_LANDMARKS], sq[EAGLE_N_LANDMARKS];
     int surv[EAGLE_N_LANDMARKS];
@@ -820,6 +841,8 @@ struct FlowShared {
 __device__ void flow_filter_block(FlowShared& F, const ChainState* st, const uint8_t* frame, int h, int w, int tid)
 {
     const int n = st->lk_n;
+    if (tid < 2 * n) { F.nxt[tid] = st->lk_next[tid]; F.prv[tid] = st->lk_prev[tid]; }
+    if (tid < n) { F.status[tid] = st->lk_status[tid]; F.lab[tid] = st->prev[tid].label; }
     for (int t = tid; t < 2 * n; t += POST_T) {
         const int p = t >> 1;
         const float* q = (t & 1) ? st->lk_prev : st->lk_next;
@@ -829,8 +852,8 @@ __device__ void flow_filter_block(FlowShared& F, const ChainState* st, const uin
     if (tid == 0) {
         int c = 0;
         for (int p = 0; p < n; ++p)
-            if (st->lk_status[p]) {
-                const float dx = st->lk_next[2 * p] - st->lk_prev[2 * p], dy = st->lk_next[2 * p + 1] - st->lk_prev[2 * p + 1];
+            if (F.status[p]) {
+                const float dx = F.nxt[2 * p] - F.prv[2 * p], dy = F.nxt[2 * p + 1] - F.prv[2 * p + 1];
                 const float sx = dx * dx, sy = dy * dy;
                 F.move[c] = sqrtf(sx + sy);                        // np.linalg.norm(axis=1) on float32
                 F.surv[c++] = p;
@@ -845,8 +868,8 @@ __device__ void flow_filter_block(FlowShared& F, const ChainState* st, const uin
                 const float z = (F.move[j] - mean) / sd;
                 if (z > 2.f) continue;
                 if (fabs(F.hue[2 * p] - F.hue[2 * p + 1]) > 25.0) continue;
-                EagleKeypoint e; e.label = st->prev[j].label;      // keys[j] of the unfiltered dict
-                e.x = (int)st->lk_next[2 * p]; e.y = (int)st->lk_next[2 * p + 1]; e.score = 0.f;
+                EagleKeypoint e; e.label = F.lab[j];               // keys[j] of the unfiltered dict
+                e.x = (int)F.nxt[2 * p]; e.y = (int)F.nxt[2 * p + 1]; e.score = 0.f;
                 e.synthesized = 0; e.on_plane = 0; e.inlier = 0; e.pad = 1;
                 F.flow[nf++] = e;
             }
@@ -866,16 +889,6 @@ __device__ int dict_merge(EagleKeypoint* dst, int nd, const EagleKeypoint* src, 
         dst[slot] = src[s];
     }
     return nd;
-}
-
-__device__ int mem_to_kp(const MemList& m, EagleKeypoint* out)
-{
-    for (int k = 0; k < m.n; ++k) {
-        EagleKeypoint e; e.label = m.kp[k].label; e.x = m.kp[k].x; e.y = m.kp[k].y; e.score = m.kp[k].score;
-        e.synthesized = 0; e.on_plane = 0; e.inlier = 0; e.pad = 0;
-        out[k] = e;
-    }
-    return m.n > 0 ? m.n : 0;
 }
 
 // calibrate_keypoints (cm.py:520-555): move a dark key-point to the brightest pixel (V = max(B,G,R)) of the 6x6 grid around it.
@@ -919,43 +932,61 @@ __global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
     EagleFrameResult* R = a.recs + i;
     const uint8_t* frame = a.cv.bgr + (size_t)i * a.cv.h * a.cv.w * 3;
     const bool have_flow = st->lk_valid != 0;
+    // mem[i] -> LDS (one entry per thread)
+    const int Mn = a.mem[i].n;
+    if (tid < Mn) {
+        const EagleFlowKp m = a.mem[i].kp[tid];
+        EagleKeypoint e; e.label = m.label; e.x = m.x; e.y = m.y; e.score = m.score;
+        e.synthesized = 0; e.on_plane = 0; e.inlier = 0; e.pad = 0;
+        C.tmp[tid] = e;
+    }
     if (have_flow) flow_filter_block(C.F, st, frame, a.cv.h, a.cv.w, tid);
+    else __syncthreads();
     if (tid == 0) {
         // key-points of this frame (cm.py:282-324)
-        const MemList& M = a.mem[i];
+        const int nm = Mn > 0 ? Mn : 0;
         const int nf = have_flow ? C.F.nflow : 0;
         const bool scheduled = i == 0 || i % a.kint == 0;
         int nkp = 0, stop = 0;
         if (scheduled) {
-            if (M.n < 0) stop = 1;                                   // the caller detects scheduled frames up front
+            if (Mn < 0) stop = 1;                                    // the caller detects scheduled frames up front
             else {
-                nkp = mem_to_kp(M, S.kp);
-                if (M.n < 4 && i > 0) nkp = dict_merge(S.kp, nkp, C.F.flow, nf);           // {**keypoints, **optical_flow_keypoints}
+                for (int k = 0; k < nm; ++k) S.kp[k] = C.tmp[k];
+                nkp = nm;
+                if (Mn < 4 && i > 0) nkp = dict_merge(S.kp, nkp, C.F.flow, nf);            // {**keypoints, **optical_flow_keypoints}
             }
         } else if (nf < 4) {
-            if (M.n < 0) stop = 1;                                   // on-demand detection (cm.py:317)
-            else { nkp = mem_to_kp(M, S.kp); nkp = dict_merge(S.kp, nkp, C.F.flow, nf); }
+            if (Mn < 0) stop = 1;                                    // on-demand detection (cm.py:317)
+            else {
+                for (int k = 0; k < nm; ++k) S.kp[k] = C.tmp[k];
+                nkp = dict_merge(S.kp, nm, C.F.flow, nf);
+            }
         } else {
             for (int k = 0; k < nf; ++k) S.kp[k] = C.F.flow[k];
             nkp = nf;
         }
+        if (!stop && Mn >= 0) nkp = dict_merge(S.kp, nkp, C.tmp, nm);                      // {**keypoints, **mem.get(i, {})}
+        if (stop) st->stalled = i;
+        S.nkp = stop ? 0 : nkp;
+        C.stop = stop;
+    }
+    __syncthreads();
+    if (C.stop) return;
+    synthesize_block(S.syn, S.kp, &S.nkp, tid);                      // cm.py:325-326
+    if (tid == 0) {
+        int stop = 0;
+        if (a.calib && !calibrate_keypoints(S.kp, S.nkp, frame, a.cv.h, a.cv.w)) { st->error = 1 + i; stop = 2; }
         if (!stop) {
-            if (M.n >= 0) { const int nm = mem_to_kp(M, C.tmp); nkp = dict_merge(S.kp, nkp, C.tmp, nm); }   // {**keypoints, **mem.get(i, {})}
-            if (nkp >= 2) nkp = synthesize_keypoints(S.kp, nkp);
-            if (a.calib && !calibrate_keypoints(S.kp, nkp, frame, a.cv.h, a.cv.w)) { st->error = 1 + i; stop = 2; }
-        }
-        if (stop == 1) st->stalled = i;
-        if (!stop) {
-            S.nkp = nkp;
-            st->n_prev = nkp;                                        // prev_keypoints = keypoints (cm.py:329)
-            for (int k = 0; k < nkp; ++k) { EagleFlowKp e; e.label = S.kp[k].label; e.x = S.kp[k].x; e.y = S.kp[k].y; e.score = S.kp[k].score; st->prev[k] = e; }
             C.attempt = (i % a.hint == 0) || st->compute_h;
-            S.npts = C.attempt ? select_plane_points(S.kp, nkp, S.img, S.world, S.used) : 0;
+            S.npts = C.attempt ? select_plane_points(S.kp, S.nkp, S.img, S.world, S.used) : 0;
         }
         C.stop = stop;
     }
     __syncthreads();
     if (C.stop) return;
+    const int nkp = S.nkp;
+    if (tid == 0) st->n_prev = nkp;                                  // prev_keypoints = keypoints (cm.py:329)
+    if (tid < nkp) { EagleFlowKp e; e.label = S.kp[tid].label; e.x = S.kp[tid].x; e.y = S.kp[tid].y; e.score = S.kp[tid].score; st->prev[tid] = e; }
     if (C.attempt) {
         find_homography_block(S.hs, a.rng_raw, S.img, S.world, S.npts, pp.ransac_thresh, pp.ransac_max_iters, pp.lm_iters);
         __syncthreads();
@@ -980,9 +1011,9 @@ __global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
         S.H_ok = Hok;
         R->H_valid = Hok; R->pad[0] = (uint8_t)own; R->pad[1] = 0;
         R->n_kp = S.nkp;
-        for (int k = 0; k < EAGLE_N_LANDMARKS; ++k) { R->hm_idx[k] = 0; R->hm_score[k] = 0.f; }
         write_bounds(R, S.H, Hok, pp.frame_h, pp.frame_w);
     }
+    if (tid < EAGLE_N_LANDMARKS) { R->hm_idx[tid] = 0; R->hm_score[tid] = 0.f; }
     __syncthreads();
     for (int k = tid; k < S.nkp; k += POST_T) R->kp[k] = S.kp[k];
     project_detections(R, S.H, S.H_ok != 0, tid);

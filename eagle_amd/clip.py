@@ -1,10 +1,11 @@
 """Host sequencing of the reference loop in a stateful key-point cadence (eagle/models/coordinate_model.py:188-416 with
 keypoint_interval > 1 and/or calibration) over the clip session of the C ABI (include/eagle.h, eagle_clip_*).
 
-What runs where: the detector on every frame and HRNet on every keypoint_interval-th frame in batches, the gray pyramids of all
-frames, then ONE pyramidal-LK launch and ONE loop-body launch per frame, stream-ordered, without host round trips.  The host
-steps in only where the reference itself leaves its cadence: the first-frame search (cm.py:289-311) and on-demand detections
-(cm.py:317), after which the chain resumes at the frame that asked."""
+What runs where: the gray pyramids of all frames; per chunk of frames the detector on every frame and HRNet on every
+keypoint_interval-th frame, in batches, on two streams; and on a third stream ONE pyramidal-LK launch and ONE loop-body launch per
+frame, stream-ordered, without host round trips — the network passes of chunk c+1 overlap the sequential loop of chunk c.  The
+host steps in only where the reference itself leaves its cadence: the first-frame search (cm.py:289-311) and on-demand detections
+(cm.py:317), after which the loop resumes at the frame that asked."""
 import numpy as np
 
 from . import lib
@@ -27,17 +28,22 @@ def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=Fal
 
     try:
         h.clip_open(dptr, n)
-        detect(0, keypoint_interval, (n + keypoint_interval - 1) // keypoint_interval)        # cm.py:217-276
-        m0 = h.clip_get_keypoints(0)
-        if len(m0) < 4 and n > 1:
-            _first_frame_search(h, n, m0, detect)
-        first = 0
-        while True:
-            stalled = h.clip_run(first, keypoint_interval, homography_interval, calibration)
-            if stalled < 0:
-                break
-            detect(stalled)                                                                   # cm.py:317 on-demand detection
-            first = stalled
+        # chunks of batch * keypoint_interval frames: one full HRNet batch of scheduled frames per chunk.  Everything below is
+        # enqueued asynchronously: the detector / HRNet passes of chunk c+1 run under the sequential loop of chunk c.
+        chunk = max(1, int(h.cfg.batch)) * keypoint_interval
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            h.clip_detect_objects(c0, c1 - c0)
+            detect(c0, keypoint_interval, (c1 - c0 + keypoint_interval - 1) // keypoint_interval)       # cm.py:217-276
+            if c0 == 0:
+                m0 = h.clip_get_keypoints(0)
+                if len(m0) < 4 and n > 1:
+                    _first_frame_search(h, n, m0, detect)
+            h.clip_run(c0, c1, keypoint_interval, homography_interval, calibration, wait=False)
+        stalled = h.clip_run(n, n, keypoint_interval, homography_interval, calibration, wait=True)
+        while stalled >= 0:
+            detect(stalled)                                                                          # cm.py:317 on-demand detection
+            stalled = h.clip_run(stalled, n, keypoint_interval, homography_interval, calibration, wait=True)
         recs = h.clip_fetch(n)
     finally:
         h.clip_close()

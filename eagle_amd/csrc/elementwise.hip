@@ -66,14 +66,15 @@ __device__ __forceinline__ void store_px(const TView& v, size_t pix, float r, fl
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* bgr, int n, int h, int w, TView kp, TView det, LetterBox lb)
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* bgr, int n, int h, int w, TView kp, TView det, LetterBox lb, int which)
 {
     const size_t fsz = (size_t)h * w * 3;
     const int kp_px = kp.h * kp.w, det_px = det.h * det.w;
-    const int per = kp_px + det_px;
+    const int lo = (which & 1) ? 0 : kp_px, hi = (which & 2) ? kp_px + det_px : kp_px;      // which: 1 = key-point tensor, 2 = detector tensor
+    const int per = hi - lo;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * per; i += (size_t)gridDim.x * blockDim.x) {
         const int f = (int)(i / per);
-        int r = (int)(i - (size_t)f * per);
+        int r = lo + (int)(i - (size_t)f * per);
         const uint8_t* src = bgr + f * fsz;
         int rgb[3];
         if (r < kp_px) {
@@ -108,12 +109,13 @@ LetterBox letterbox_geometry(int h, int w, int imgsz)
 }
 
 void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det,
-                       const LetterBox& lb, hipStream_t s)
+                       const LetterBox& lb, hipStream_t s, int which)
 {
-    const size_t total = (size_t)n * (kp.h * kp.w + det.h * det.w);
+    const size_t total = (size_t)n * (((which & 1) ? kp.h * kp.w : 0) + ((which & 2) ? det.h * det.w : 0));
+    if (total == 0) return;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
-    if (precision == EAGLE_PREC_F16) hipLaunchKernelGGL(preprocess_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb);
-    else hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb);
+    if (precision == EAGLE_PREC_F16) hipLaunchKernelGGL(preprocess_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
+    else hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
     HIP_CHECK(hipGetLastError());
 }
 

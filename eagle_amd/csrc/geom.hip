@@ -879,13 +879,15 @@ __device__ void flow_filter_block(FlowShared& F, const ChainState* st, const uin
     __syncthreads();
 }
 
-// {**dst, **src}: values of src win, new keys are appended in src order
+// {**dst, **src}: values of src win, new keys are appended in src order (one pass over each dict through a label -> slot map)
 __device__ int dict_merge(EagleKeypoint* dst, int nd, const EagleKeypoint* src, int ns)
 {
+    signed char slot_of[EAGLE_N_LANDMARKS];
+    for (int k = 0; k < EAGLE_N_LANDMARKS; ++k) slot_of[k] = -1;
+    for (int k = 0; k < nd; ++k) slot_of[dst[k].label] = (signed char)k;
     for (int s = 0; s < ns; ++s) {
-        int slot = -1;
-        for (int k = 0; k < nd; ++k) if (dst[k].label == src[s].label) { slot = k; break; }
-        if (slot < 0) slot = nd++;
+        int slot = slot_of[src[s].label];
+        if (slot < 0) { slot = nd++; slot_of[src[s].label] = (signed char)slot; }
         dst[slot] = src[s];
     }
     return nd;

@@ -121,7 +121,10 @@ struct EagleHandle {
         MemList* mem = nullptr;
         ChainState* st = nullptr;          // loop state
         ChainState* st_op = nullptr;       // scratch state of eagle_clip_flow
-        ChainState* h_st = nullptr;        // pinned staging
+        ChainState* h_st = nullptr;        // pinned staging of eagle_clip_flow
+        ChainState* h_zero = nullptr;      // pinned: the initial loop state
+        int* h_tail = nullptr;             // pinned: {stalled, error} read-back, [2] = the constant -1
+        hipEvent_t ev_gray = nullptr, ev_det = nullptr, ev_kp = nullptr;
     } clip;
     // comm
     void* rccl = nullptr; void* comm = nullptr; int rank = 0, world = 1;
@@ -582,28 +585,31 @@ static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage sta
 }
 
 // ---- clip session (optical-flow cadence) ----------------------------------------------------------------------------------
+// Three streams: s_det runs the detector pass, s_main the HRNet pass (+ gray pyramids, operator calls), s_post the sequential
+// loop body (K12 + K13 per frame).  The passes of later frames overlap the loop of earlier ones; events order them.
+static void clip_sync(EagleHandle* h)
+{
+    HIP_CHECK(hipStreamSynchronize(h->s_det));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_post));
+}
+
 static void clip_close(EagleHandle* h)
 {
     EagleHandle::Clip& c = h->clip;
+    if (c.open) { (void)hipStreamSynchronize(h->s_det); (void)hipStreamSynchronize(h->s_main); (void)hipStreamSynchronize(h->s_post); }
     for (auto& p : c.g) { if (p) (void)hipFree(p); p = nullptr; }
     if (c.recs) (void)hipFree(c.recs);
     if (c.mem) (void)hipFree(c.mem);
     if (c.st) (void)hipFree(c.st);
     if (c.st_op) (void)hipFree(c.st_op);
     if (c.h_st) (void)hipHostFree(c.h_st);
+    if (c.h_zero) (void)hipHostFree(c.h_zero);
+    if (c.h_tail) (void)hipHostFree(c.h_tail);
+    for (hipEvent_t e : {c.ev_gray, c.ev_det, c.ev_kp}) if (e) (void)hipEventDestroy(e);
     c = EagleHandle::Clip();
 }
 
-static void clip_reset_state(EagleHandle* h, ChainState* d)
-{
-    ChainState& z = *h->clip.h_st;
-    memset(&z, 0, sizeof(z));
-    z.stalled = -1;
-    HIP_CHECK(hipMemcpyAsync(d, &z, sizeof(z), hipMemcpyHostToDevice, h->s_main));
-    HIP_CHECK(hipStreamSynchronize(h->s_main));
-}
-
-// detector + decode + NMS + object rules of every frame (cm.py:331 detect_objects), records kept in HBM
 static void clip_open(EagleHandle* h, const uint8_t* d_bgr, int n)
 {
     clip_close(h);
@@ -616,39 +622,57 @@ static void clip_open(EagleHandle* h, const uint8_t* d_bgr, int n)
         if (c.cv.lw[l] <= 15 || c.cv.lh[l] <= 15) break;
         c.cv.levels = l;
     }
+    c.open = true;
     for (int l = 0; l < 3; ++l) {
         HIP_CHECK(hipMalloc((void**)&c.g[l], std::max<size_t>((size_t)n * c.cv.lh[l] * c.cv.lw[l], 16)));
         c.cv.g[l] = c.g[l];
     }
-    HIP_CHECK(hipMalloc((void**)&c.recs, sizeof(EagleFrameResult) * (size_t)std::max(n, 1)));
-    HIP_CHECK(hipMalloc((void**)&c.mem, sizeof(MemList) * (size_t)std::max(n, 1)));
+    const size_t nn = (size_t)std::max(n, 1);
+    HIP_CHECK(hipMalloc((void**)&c.recs, sizeof(EagleFrameResult) * nn));
+    HIP_CHECK(hipMalloc((void**)&c.mem, sizeof(MemList) * nn));
     HIP_CHECK(hipMalloc((void**)&c.st, sizeof(ChainState)));
     HIP_CHECK(hipMalloc((void**)&c.st_op, sizeof(ChainState)));
     HIP_CHECK(hipHostMalloc((void**)&c.h_st, sizeof(ChainState), hipHostMallocDefault));
-    c.open = true;
-    HIP_CHECK(hipMemsetAsync(c.mem, 0xFF, sizeof(MemList) * (size_t)std::max(n, 1), h->s_main));      // n = -1 everywhere
-    clip_reset_state(h, c.st);
-    if (n == 0) return;
-    gray_pyramid_launch(d_bgr, n, c.cv.h, c.cv.w, c.g[0], c.g[1], c.g[2], h->s_main);
+    HIP_CHECK(hipHostMalloc((void**)&c.h_zero, sizeof(ChainState), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&c.h_tail, sizeof(int) * 4, hipHostMallocDefault));
+    memset(c.h_zero, 0, sizeof(ChainState));
+    c.h_zero->stalled = -1;
+    c.h_tail[0] = -1; c.h_tail[1] = 0; c.h_tail[2] = -1;
+    for (hipEvent_t* e : {&c.ev_gray, &c.ev_det, &c.ev_kp}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    HIP_CHECK(hipMemsetAsync(c.mem, 0xFF, sizeof(MemList) * nn, h->s_main));                  // n = -1 everywhere
+    HIP_CHECK(hipMemsetAsync(c.recs, 0, sizeof(EagleFrameResult) * nn, h->s_main));
+    HIP_CHECK(hipMemcpyAsync(c.st, c.h_zero, sizeof(ChainState), hipMemcpyHostToDevice, h->s_main));
+    if (n > 0) gray_pyramid_launch(d_bgr, n, c.cv.h, c.cv.w, c.g[0], c.g[1], c.g[2], h->s_main);
+    HIP_CHECK(hipEventRecord(c.ev_gray, h->s_main));
+    HIP_CHECK(hipStreamWaitEvent(h->s_det, c.ev_gray, 0));       // the record memset precedes the first detector write
+    HIP_CHECK(hipEventRecord(c.ev_det, h->s_det));
+    HIP_CHECK(hipEventRecord(c.ev_kp, h->s_main));
+}
+
+// detector + decode + NMS + object rules of frames [first, first+count) (cm.py:331 detect_objects), records kept in HBM; asynchronous
+static void clip_detect_objects(EagleHandle* h, int first, int count)
+{
+    const EagleConfig& cf = h->cfg;
+    EagleHandle::Clip& c = h->clip;
     const int B = cf.batch;
     const size_t fb = (size_t)cf.frame_h * cf.frame_w * 3;
     size_t ev_i = 0;
     EagleHandle::StepBuf& sb = h->sb[0];
     const bool prof = h->prof; h->prof = false;
-    for (int i = 0; i < n; i += B) {
-        const int na = std::min(B, n - i);
-        HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
-        preprocess_launch(h->prec, d_bgr + (size_t)i * fb, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
-        run_net(h, h->yo.get(), h->s_main, ev_i);
-        yolo_decode_launch(h->levels, 3, B, 5, cf.detector_floor, h->ds, h->s_main);
-        nms_launch(h->ds, B, h->pp, sb.d_out, h->s_main);
-        HIP_CHECK(hipMemcpyAsync(c.recs + i, sb.d_out, sizeof(EagleFrameResult) * na, hipMemcpyDeviceToDevice, h->s_main));
+    for (int i = first; i < first + count; i += B) {
+        const int na = std::min(B, first + count - i);
+        HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_det));
+        preprocess_launch(h->prec, c.cv.bgr + (size_t)i * fb, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_det, 2);
+        run_net(h, h->yo.get(), h->s_det, ev_i);
+        yolo_decode_launch(h->levels, 3, B, 5, cf.detector_floor, h->ds, h->s_det);
+        nms_launch(h->ds, B, h->pp, sb.d_out, h->s_det);
+        HIP_CHECK(hipMemcpyAsync(c.recs + i, sb.d_out, sizeof(EagleFrameResult) * na, hipMemcpyDeviceToDevice, h->s_det));
     }
     h->prof = prof;
-    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    HIP_CHECK(hipEventRecord(c.ev_det, h->s_det));
 }
 
-// HRNet + heat-map maxima + decode of frames first, first+stride, ... -> mem[]
+// HRNet + heat-map maxima + decode of frames first, first+stride, ... -> mem[]; asynchronous
 static void clip_detect_keypoints(EagleHandle* h, int first, int stride, int count)
 {
     const EagleConfig& cf = h->cfg;
@@ -667,13 +691,13 @@ static void clip_detect_keypoints(EagleHandle* h, int first, int stride, int cou
                 HIP_CHECK(hipMemcpyAsync(sb.d_frames + (size_t)k * fb, c.cv.bgr + (size_t)(first + (k0 + k) * stride) * fb, fb, hipMemcpyDeviceToDevice, h->s_main));
             src = sb.d_frames;
         }
-        preprocess_launch(h->prec, src, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
+        preprocess_launch(h->prec, src, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_main, 1);
         run_net(h, h->hr.get(), h->s_main, ev_i);
         heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
         decode_mem_launch(sb.parts, na, h->pp, c.mem, first + k0 * stride, stride, h->s_main);
     }
     h->prof = prof;
-    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    HIP_CHECK(hipEventRecord(c.ev_kp, h->s_main));
 }
 
 static void finalize(EagleHandle* h)
@@ -924,6 +948,15 @@ int eagle_clip_close(EagleHandle* h)
     API_END(h)
 }
 
+int eagle_clip_detect_objects(EagleHandle* h, int first, int count)
+{
+    CLIP_CHECK(h, h->clip.open && first >= 0 && count >= 0 && first + (int64_t)count <= h->clip.cv.n, "eagle_clip_detect_objects: no open clip or frames out of range")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    eagle::clip_detect_objects(h, first, count);
+    API_END(h)
+}
+
 int eagle_clip_detect_keypoints(EagleHandle* h, int first, int stride, int count)
 {
     CLIP_CHECK(h, h->clip.open && first >= 0 && stride >= 1 && count >= 0 && (count == 0 || first + (int64_t)(count - 1) * stride < h->clip.cv.n),
@@ -939,6 +972,7 @@ int eagle_clip_get_keypoints(EagleHandle* h, int frame, EagleFlowKp* out, int* n
     CLIP_CHECK(h, h->clip.open && frame >= 0 && frame < h->clip.cv.n && out && n, "eagle_clip_get_keypoints: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
     MemList m;
     HIP_CHECK(hipMemcpy(&m, h->clip.mem + frame, sizeof(m), hipMemcpyDeviceToHost));
     *n = m.n;
@@ -952,6 +986,7 @@ int eagle_clip_set_keypoints(EagleHandle* h, int frame, const EagleFlowKp* in, i
                "eagle_clip_set_keypoints: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
     MemList m; memset(&m, 0, sizeof(m));
     m.n = n;
     for (int k = 0; k < n; ++k) m.kp[k] = in[k];
@@ -986,27 +1021,32 @@ int eagle_clip_flow(EagleHandle* h, int src_frame, int dst_frame, int hue_frame,
     API_END(h)
 }
 
-int eagle_clip_run(EagleHandle* h, int first, int keypoint_interval, int homography_interval, int calibration, int* stalled_at)
+int eagle_clip_run(EagleHandle* h, int first, int last, int keypoint_interval, int homography_interval, int calibration, int wait, int* stalled_at)
 {
-    CLIP_CHECK(h, h->clip.open && first >= 0 && first <= h->clip.cv.n && keypoint_interval >= 1 && homography_interval >= 1 && stalled_at,
+    CLIP_CHECK(h, h->clip.open && first >= 0 && first <= last && last <= h->clip.cv.n && keypoint_interval >= 1 && homography_interval >= 1,
                "eagle_clip_run: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
     EagleHandle::Clip& c = h->clip;
-    if (first == 0) eagle::clip_reset_state(h, c.st);
-    else {                                                // resume after an on-demand detection
-        int clear = -1;
-        HIP_CHECK(hipMemcpyAsync((char*)c.st + offsetof(ChainState, stalled), &clear, sizeof(int), hipMemcpyHostToDevice, h->s_main));
+    hipStream_t sp = h->s_post;
+    HIP_CHECK(hipStreamWaitEvent(sp, c.ev_gray, 0));
+    HIP_CHECK(hipStreamWaitEvent(sp, c.ev_det, 0));       // every detector / HRNet pass enqueued so far
+    HIP_CHECK(hipStreamWaitEvent(sp, c.ev_kp, 0));
+    if (first < last) {
+        if (first == 0) HIP_CHECK(hipMemcpyAsync(c.st, c.h_zero, sizeof(ChainState), hipMemcpyHostToDevice, sp));
+        else HIP_CHECK(hipMemcpyAsync((char*)c.st + offsetof(ChainState, stalled), &c.h_tail[2], sizeof(int), hipMemcpyHostToDevice, sp));   // resume
     }
-    for (int i = first; i < c.cv.n; ++i) {
-        lk_launch(c.cv, i > 0 ? i - 1 : 0, i, c.st, c.mem, keypoint_interval, h->s_main);
-        chain_launch(c.cv, c.st, c.mem, c.recs, h->pp, i, keypoint_interval, homography_interval, calibration, h->s_main);
+    for (int i = first; i < last; ++i) {
+        lk_launch(c.cv, i > 0 ? i - 1 : 0, i, c.st, c.mem, keypoint_interval, sp);
+        chain_launch(c.cv, c.st, c.mem, c.recs, h->pp, i, keypoint_interval, homography_interval, calibration, sp);
     }
-    int tail[2] = {-1, 0};
-    HIP_CHECK(hipMemcpyAsync(tail, (char*)c.st + offsetof(ChainState, stalled), sizeof(tail), hipMemcpyDeviceToHost, h->s_main));
-    HIP_CHECK(hipStreamSynchronize(h->s_main));
-    *stalled_at = tail[0];
-    if (tail[1]) { h->err = "the reference raises IndexError in calibrate_keypoints at frame " + std::to_string(tail[1] - 1); return EAGLE_E_REFERENCE_RAISES; }
+    if (stalled_at) *stalled_at = -1;
+    if (wait) {
+        HIP_CHECK(hipMemcpyAsync(c.h_tail, (char*)c.st + offsetof(ChainState, stalled), sizeof(int) * 2, hipMemcpyDeviceToHost, sp));
+        HIP_CHECK(hipStreamSynchronize(sp));
+        if (stalled_at) *stalled_at = c.h_tail[0];
+        if (c.h_tail[1]) { h->err = "the reference raises IndexError in calibrate_keypoints at frame " + std::to_string(c.h_tail[1] - 1); return EAGLE_E_REFERENCE_RAISES; }
+    }
     API_END(h)
 }
 
@@ -1015,6 +1055,7 @@ int eagle_clip_fetch(EagleHandle* h, EagleFrameResult* out)
     CLIP_CHECK(h, h->clip.open && (out || h->clip.cv.n == 0), "eagle_clip_fetch: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
+    eagle::clip_sync(h);
     if (h->clip.cv.n > 0) HIP_CHECK(hipMemcpy(out, h->clip.recs, sizeof(EagleFrameResult) * (size_t)h->clip.cv.n, hipMemcpyDeviceToHost));
     API_END(h)
 }

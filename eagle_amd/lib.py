@@ -81,7 +81,8 @@ def load():
     L.eagle_clip_get_keypoints.argtypes = [vp, i32, vp, C.POINTER(i32)]
     L.eagle_clip_set_keypoints.argtypes = [vp, i32, vp, i32]
     L.eagle_clip_flow.argtypes = [vp, i32, i32, i32, vp, i32, vp, C.POINTER(i32), fp, u8p]
-    L.eagle_clip_run.argtypes = [vp, i32, i32, i32, i32, C.POINTER(i32)]
+    L.eagle_clip_run.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(i32)]
+    L.eagle_clip_detect_objects.argtypes = [vp, i32, i32]
     L.eagle_clip_fetch.argtypes = [vp, vp]
     L.eagle_comm_id.argtypes = [vp]
     L.eagle_comm_init.argtypes = [vp, i32, i32, vp]
@@ -100,7 +101,7 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_finalize_weights", "eagle_process_frames", "eagle_process_device_frames", "eagle_device_alloc",
            "eagle_device_free", "eagle_device_upload", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
-           "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
+           "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
            "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch"]
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
@@ -208,6 +209,9 @@ class Handle:
     def clip_close(self):
         self._check(self.L.eagle_clip_close(self._h), "clip_close")
 
+    def clip_detect_objects(self, first, count):
+        self._check(self.L.eagle_clip_detect_objects(self._h, first, count), "clip_detect_objects")
+
     def clip_detect_keypoints(self, first, stride=1, count=1):
         self._check(self.L.eagle_clip_detect_keypoints(self._h, first, stride, count), "clip_detect_keypoints")
 
@@ -230,10 +234,11 @@ class Handle:
                                            out.ctypes.data_as(C.c_void_p), C.byref(n), _fp(nxt), st.ctypes.data_as(C.POINTER(C.c_uint8))), "clip_flow")
         return (out[: n.value].copy(), nxt[: len(kps)], st[: len(kps)]) if raw else out[: n.value].copy()
 
-    def clip_run(self, first, keypoint_interval, homography_interval, calibration=False):
-        """Runs the loop body for frames first.. on the GPU; -> index of a frame that needs an on-demand detection, or -1."""
+    def clip_run(self, first, last, keypoint_interval, homography_interval, calibration=False, wait=True):
+        """Enqueues the loop body for frames [first, last) on the GPU; wait=True -> index of a frame that needs an on-demand
+        detection, or -1 when every frame enqueued so far is done."""
         stalled = C.c_int(-1)
-        rc = self.L.eagle_clip_run(self._h, first, keypoint_interval, homography_interval, int(calibration), C.byref(stalled))
+        rc = self.L.eagle_clip_run(self._h, first, last, keypoint_interval, homography_interval, int(calibration), int(wait), C.byref(stalled))
         if rc == E_REFERENCE_RAISES:
             raise IndexError(self.L.eagle_last_error(self._h).decode())
         self._check(rc, "clip_run")

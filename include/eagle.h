@@ -139,23 +139,28 @@ int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double*
  * The reference detects key-points with HRNet only every keypoint_interval-th frame and propagates them with
  * cv2.calcOpticalFlowPyrLK in between (cm.py:313-322, 419-478); that makes the loop sequential over a clip.  A clip session
  * keeps the clip, its gray pyramids, every frame's detections and the loop-carried state in HBM:
- *   eagle_clip_open             gray pyramids of all frames + detector / NMS / object rules on all frames       (cm.py:280, 331)
- *   eagle_clip_detect_keypoints HRNet + decode on frames first, first+stride, ... -> their mem[] entries        (cm.py:217-276, 285, 317)
+ *   eagle_clip_open             gray pyramids of all frames                                                      (cm.py:280)
+ *   eagle_clip_detect_objects   detector / NMS / object rules on frames [first, first+count), asynchronous      (cm.py:331)
+ *   eagle_clip_detect_keypoints HRNet + decode on frames first, first+stride, ... -> their mem[] entries, asynchronous (cm.py:217-276, 285, 317)
  *   eagle_clip_get/set_keypoints read / replace mem[frame]  (the first-frame search of cm.py:289-311 is sequenced by the caller)
  *   eagle_clip_flow             calculate_optical_flow(frames[hue_frame], gray[src], kps, gray[dst]) as an operator (cm.py:419-478)
- *   eagle_clip_run              the loop body for frames first..n-1, in order, on the GPU without host round trips; stops early
- *                               at a frame that needs a model detection it does not have (*stalled_at = frame, else -1)
+ *   eagle_clip_run              the loop body for frames [first, last), in order, on the GPU without host round trips, on its own
+ *                               stream behind every pass enqueued so far (so the passes of later frames overlap it); it stops itself
+ *                               at a frame that needs a model detection it does not have.  wait = 1: block and report that frame
+ *                               (*stalled_at, else -1); first > 0 resumes the loop state of the previous call
  *   eagle_clip_fetch            the n records.  EagleFrameResult.pad[0] = 1 when the frame solved its own homography
  *                               ("Keypoints" = its inliers, cm.py:359-362); kp[].pad bit 0: the value came from the flow, bit 1: moved by the calibration
  *                               (both are numpy integers in the reference's dict, which json.dump(default=float) writes as floats). */
 typedef struct EagleFlowKp { int32_t label; int32_t x, y; float score; } EagleFlowKp;
 int eagle_clip_open(EagleHandle* h, const void* d_bgr, int n);
+int eagle_clip_detect_objects(EagleHandle* h, int first, int count);
 int eagle_clip_detect_keypoints(EagleHandle* h, int first, int stride, int count);
 int eagle_clip_get_keypoints(EagleHandle* h, int frame, EagleFlowKp* out /* EAGLE_N_LANDMARKS */, int* n /* -1: no entry */);
 int eagle_clip_set_keypoints(EagleHandle* h, int frame, const EagleFlowKp* in, int n);
 int eagle_clip_flow(EagleHandle* h, int src_frame, int dst_frame, int hue_frame, const EagleFlowKp* in, int n_in,
                     EagleFlowKp* out /* EAGLE_N_LANDMARKS */, int* n_out, float* next_pts /* 2*n_in or NULL */, uint8_t* status /* n_in or NULL */);
-int eagle_clip_run(EagleHandle* h, int first, int keypoint_interval, int homography_interval, int calibration, int* stalled_at);
+int eagle_clip_run(EagleHandle* h, int first, int last, int keypoint_interval, int homography_interval, int calibration, int wait,
+                   int* stalled_at);
 int eagle_clip_fetch(EagleHandle* h, EagleFrameResult* out);
 int eagle_clip_close(EagleHandle* h);
 #define EAGLE_E_REFERENCE_RAISES (-7) /* the reference raises IndexError here (calibration grid at the image border, cm.py:545) */

@@ -72,3 +72,29 @@ def init_rccl(handle, rank, world):
         uid = uid.cuda()
     dist.broadcast(uid, 0)
     handle.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+
+# ---- stateful cadences (optical-flow key-point propagation, eagle_amd/clip.py): shard by CLIP ---------------------------------
+# With keypoint_interval > 1 frame i depends on frame i-1 (cm.py:207-213: prev_keypoints, prev_gray, the homography and its retry
+# flag), so a clip is the unit of work (BASELINE.json configs[4]: 8 clips on 8 GPUs).  Rank r owns the contiguous range of clips
+# shard_range(n_clips, r, world); the one collective is again an all-gather of fixed-size records, here of ragged per-rank totals.
+def gather_clip_records(local_clips, clip_lengths, rank, world, handle=None, transport="rccl"):
+    """local_clips: this rank's clips' records (list of structured arrays, in clip order); clip_lengths: frames of EVERY clip.
+    Returns the records of all clips (list, clip order) on every rank."""
+    n_clips = len(clip_lengths)
+    lo, hi = shard_range(n_clips, rank, world)
+    assert len(local_clips) == hi - lo and [len(c) for c in local_clips] == list(clip_lengths[lo:hi])
+    if world == 1:
+        return [np.ascontiguousarray(c) for c in local_clips]
+    totals = [sum(clip_lengths[slice(*shard_range(n_clips, r, world))]) for r in range(world)]
+    c = max(max(totals), 1)
+    local = np.concatenate(local_clips) if local_clips else np.zeros(0, RESULT_DTYPE)
+    allr = gather_records(_pad(local, c), c * world, rank, world, handle=handle, transport=transport)
+    out = []
+    for r in range(world):
+        a, b = shard_range(n_clips, r, world)
+        off = r * c
+        for k in range(a, b):
+            out.append(allr[off: off + clip_lengths[k]])
+            off += clip_lengths[k]
+    return out

@@ -86,3 +86,43 @@ def test_world_one_gather_is_identity():
     a = np.zeros(3, RESULT_DTYPE)
     a["n_det"] = [1, 2, 3]
     assert shard.gather_records(a, 3, 0, 1)["n_det"].tolist() == [1, 2, 3]
+
+
+CLIP_WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from eagle_amd import shard
+from eagle_amd.lib import RESULT_DTYPE
+lengths = [int(v) for v in sys.argv[2].split(",")]
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lo, hi = shard.shard_range(len(lengths), rank, world)
+local = []
+for c in range(lo, hi):                                # a record that identifies its clip and frame
+    a = np.zeros(lengths[c], RESULT_DTYPE)
+    a["n_det"] = c
+    a["n_kp"] = np.arange(lengths[c])
+    local.append(a)
+allc = shard.gather_clip_records(local, lengths, rank, world, transport="dist")
+assert [len(a) for a in allc] == lengths
+for c, a in enumerate(allc):
+    assert (a["n_det"] == c).all() and a["n_kp"].tolist() == list(range(lengths[c]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_clip_sharding_for_stateful_cadences(tmp_path):
+    """configs[4] shape: whole clips per rank (the optical-flow cadence is sequential within a clip), ragged totals."""
+    w = tmp_path / "clip_worker.py"
+    w.write_text(CLIP_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(w), ROOT, "5,3,9,1,4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -22,7 +22,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_FRAME = 339.0e9          # SURVEY §8d / BASELINE.md §3: 4.85 G (yolov8n@384x640) + 334.15 G (HRNet-W48@540x960)
 MFMA_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 
 
@@ -205,14 +204,14 @@ def main():
     res = None
     if rank == 0:
         res = {
-            "metric": "frames/sec end-to-end (detect+keypoint+homography) @1280x720",
+            "metric": f"frames/sec end-to-end (detect+keypoint+homography) @{a.width}x{a.height}",
             "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if a.precision == "f16" else "f32", "data": f"synthetic ({len(base)} distinct generated frames per rank tiled to {n_local}; seeded synthetic weights)",
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}",
                        "gather": "none" if world == 1 else gather_used, "hip_graph": bool(a.graph)},
-            "roofline": {"bound": "mfma", "kernel": "conv_f16_kernel / conv_f16_ws_kernel (all 356 convolution launches of a step)" if a.precision == "f16" else "conv_f32_kernel",
+            "roofline": {"bound": "mfma", "kernel": f"conv_f16_kernel / conv_f16_ws_kernel (all {n_conv // prof_steps} convolution launches of a step)" if a.precision == "f16" else "conv_f32_kernel",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3, "unit": "TFLOP/s",
                          "frac": round(achieved / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
                          "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),

@@ -908,7 +908,7 @@ static const Tuned g_tuned[] = {
 #include "conv_tuned.inc"
     {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
-ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo)
+ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue)
 {
     ConvConfig c;
     c.ks = ks; c.stride = stride; c.cin = cin_pad; c.cout_pad = cout_pad;
@@ -925,13 +925,14 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
     if (const char* f = getenv("EAGLE_CONV_FORCE")) {
         ConvConfig q = c;
         if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 &&
-            find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024)
+            find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024 && (!conv_ws(q) || plain_epilogue))
             return q;
     }
     // fp16: per-layer table measured on MI355X (tools/autotune_conv.py); shapes not in the table use the heuristic below
     for (const Tuned& t : g_tuned)
         if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
             ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = t.variant;
+            if (conv_ws(q) && !plain_epilogue) continue;   // the weight-stationary kernel has no SiLU / second-residual / fp32-output epilogue
             if (find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
         }
     // heuristic: the (NT, KC) pair with the most work per staged item whose LDS footprint still lets two workgroups share a CU

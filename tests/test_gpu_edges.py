@@ -169,3 +169,19 @@ def test_cli_at_25_fps_uses_the_flow_cadence(tmp_path):
     assert all(set(r) == {"Coordinates", "Time", "Keypoints", "Boundaries"} for r in d.values())
     every = cli.main(["--frames", "11", "--fps", "25", "--out", str(tmp_path / "e"), "--batch", "4", "--every-frame"])
     assert every == 0 and len(json.load(open(tmp_path / "e" / "raw_coordinates.json"))) == 11
+
+
+def test_cfg3_fp16_family_builds_and_runs():
+    """configs[2] in the fp16 family: 1920x1080 frames, YOLOv8-l @960.  The tuned per-layer table must only hand a layer to a
+    kernel variant that implements its epilogue (the weight-stationary variant has no SiLU epilogue: YOLO's 64->64 3x3 layers
+    share their shape with HRNet's stem convs)."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    m = CoordinateModel(precision="f16", batch=2, frame_hw=(1080, 1920), detector="l", det_imgsz=960)
+    try:
+        frames = np.stack([synth.frame(0, 0, 1080, 1920), synth.noise_frame(1, 1080, 1920)])
+        recs = m.process_records(frames)
+        assert len(recs) == 2 and all(0 <= int(r["n_det"]) <= 300 for r in recs)
+        assert all(np.isfinite(r["hm_score"]).all() for r in recs)
+    finally:
+        m.handle.close()

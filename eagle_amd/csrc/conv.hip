@@ -152,6 +152,28 @@ __device__ __forceinline__ void f16_epilogue(const ConvArgs& a, f32x4 (&acc)[NT]
 // (weight slice + halo tile) back to back into registers and only then writes them to LDS, so a chunk costs one memory
 // round trip instead of one per staging iteration; tile shapes are chosen so that two workgroups share a CU (LDS <= 80 KiB,
 // <= 256 VGPRs) and one workgroup's MFMAs hide the other's staging.
+// Scheduling recipe of the MFMA phase (one basic block: NI steps of NT + PW ds_read_b128 and NT * PW MFMAs).  Left alone, hipcc
+// issues a step's reads right in front of the MFMAs that consume them and waits (measured: the LDS latency of every step is
+// exposed, ~20 % of the kernel).  The recipe spreads the reads of step i+1, one at a time, over the MFMAs of step i.
+template <int R_, int M_, int r> __device__ __forceinline__ void sg_step()
+{
+    if constexpr (r < R_) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        // one DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, (M_ * (r + 1)) / R_ - (M_ * r) / R_, 0);      // its share of the MFMAs
+        sg_step<R_, M_, r + 1>();
+    }
+}
+template <int NI_, int R_, int M_, int i> __device__ __forceinline__ void sg_all()
+{
+    if constexpr (i + 1 < NI_) { sg_step<R_, M_, 0>(); sg_all<NI_, R_, M_, i + 1>(); }
+}
+template <int NI_, int NT_, int PW_> __device__ __forceinline__ void mfma_phase_schedule()
+{
+    __builtin_amdgcn_sched_group_barrier(0x100, NT_ + PW_, 0);          // step 0's fragments
+    sg_all<NI_, NT_ + PW_, NT_ * PW_, 0>();
+    __builtin_amdgcn_sched_group_barrier(0x008, NT_ * PW_, 0);          // the last step's MFMAs
+}
+
 template <int KS, int S, int KC, int NT, bool PIPE, int PW>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
 {
@@ -280,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
                 for (int p = 0; p < PW; ++p)
                     acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
         }
+        mfma_phase_schedule<NI, NT, PW>();
         if (!PIPE) __syncthreads();
     }
 #undef STAGE_LOAD
@@ -506,6 +529,7 @@ __global__ __launch_bounds__(256, WGS) void conv_f16_ws_kernel(ConvArgs a)
                 for (int p = 0; p < PW; ++p)
                     acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
         }
+        mfma_phase_schedule<NI, NT, PW>();
 
         // epilogue: bias, activations and residual in the MFMA layout, fp16 into this wave's strip
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPA));

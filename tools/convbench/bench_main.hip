@@ -19,7 +19,7 @@ int main(int argc, char** argv)
     for (auto& sh : shapes) {
         const int ho = (sh.h + 2 * (sh.ks / 2) - sh.ks) / sh.s + 1, wo = (sh.w + 2 * (sh.ks / 2) - sh.ks) / sh.s + 1;
         ConvLaunch L;
-        L.cfg = conv_choose(EAGLE_PREC_F16, sh.ks, sh.s, sh.cin, sh.cout, wo);
+        L.cfg = conv_choose(EAGLE_PREC_F16, sh.ks, sh.s, sh.cin, sh.cout, wo, true);
         if (getenv("KC")) L.cfg.kc = atoi(getenv("KC"));
         if (getenv("NT")) L.cfg.nt = atoi(getenv("NT"));
         if (getenv("VAR")) L.cfg.variant = atoi(getenv("VAR"));

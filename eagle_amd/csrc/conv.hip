@@ -73,9 +73,11 @@ constexpr unsigned OOB_OFF = 0x80000000u;
 
 // Staged epilogue: every stage is ONE uniform test around straight-line code over all NT*PW*4 values of the lane (a test per
 // value, as d_act() would give, cost more instructions than the MFMAs of a narrow layer).
+// r1pre: the first residual, already loaded by the caller under the last chunk's MFMAs (nullptr: load it here)
 template <int NT, int PW>
 __device__ __forceinline__ void f16_epilogue(const ConvArgs& a, f32x4 (&acc)[NT][PW], char* strip,
-                                             int n, int oy0, int ox0, int nb, int wave, int q, int lx, int lane)
+                                             int n, int oy0, int ox0, int nb, int wave, int q, int lx, int lane,
+                                             const u32x2 (*r1pre)[PW] = nullptr)
 {
     constexpr int BN = NT * 16, GO = BN / 8, RS = BN * 2 + 16;
     const int WX = a.wx;
@@ -109,7 +111,20 @@ __device__ __forceinline__ void f16_epilogue(const ConvArgs& a, f32x4 (&acc)[NT]
         }                                                                                                              \
     }
     EP_ACT(a.pre_act)
-    EP_RES(a.r1, a.r1cs, a.r1off, true)
+    if (r1pre) {
+        if (a.r1) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int p = 0; p < PW; ++p) {
+                    const half4 rh_ = __builtin_bit_cast(half4, r1pre[tt][p]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tt][p][r] = (float)rh_[r] + acc[tt][p][r];
+                }
+        }
+    } else {
+        EP_RES(a.r1, a.r1cs, a.r1off, true)
+    }
     EP_RES(a.r2, a.r2cs, a.r2off, false)
     EP_ACT(a.post_act)
 #undef EP_ALL
@@ -274,6 +289,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
         _Pragma("unroll") for (int j = 0; j < RND; ++j)                                                                 \
             if ((R0_) + j < NPA) *(u32x4*)(lds_a + ldso[(R0_) + j < NPA ? (R0_) + j : 0]) = pa[j];                      \
     }
+    // residual prefetch: only where the registers are there (measured: +5 % on NT*PW = 12, -8 % on NT*PW = 16, which is at 252 VGPRs with it)
+    constexpr bool RPRE = KS == 3 && NT * PW <= 12;
+    u32x2 r1pre[NT][PW];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int p = 0; p < PW; ++p) r1pre[tt][p] = u32x2{0u, 0u};
     if (PIPE) STAGE_LOAD(0, 0)
     for (int ch = 0; ch < a.nchunks; ++ch) {
         if (PIPE) {
@@ -288,6 +310,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
                 STAGE_STORE(r0)
             }
             __syncthreads();
+        }
+        if (RPRE && ch == a.nchunks - 1 && a.r1) {          // the residual lands under the last chunk's MFMAs instead of stalling the epilogue
+            const rsrc_t rs_ = tensor_rsrc(a.r1);
+#pragma unroll
+            for (int p = 0; p < PW; ++p) {
+                const int s = wave * PW + p, row = s / WX, xb_ = s - row * WX;
+                const int oy = oy0 + row, ox = ox0 + xb_ * 16 + lx;
+                const unsigned vo_ = (oy < a.Ho && ox < a.Wo) ? ((unsigned)((n * a.Ho + oy) * a.Wo + ox) * (unsigned)a.r1cs + (unsigned)(a.r1off + nb * BN + q * 4)) * 2u : OOB_OFF;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) r1pre[tt][p] = __builtin_amdgcn_raw_buffer_load_b64(rs_, vo_ + tt * 32, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -311,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     // epilogue (every wave is past the barrier that follows the last chunk's MFMAs, so the operand space is free)
     if (PIPE) __syncthreads();
     constexpr int RS_ = BN * 2 + 16;
-    f16_epilogue<NT, PW>(a, acc, smem + wave * (PW * 16 * RS_), n, oy0, ox0, nb, wave, q, lx, lane);
+    f16_epilogue<NT, PW>(a, acc, smem + wave * (PW * 16 * RS_), n, oy0, ox0, nb, wave, q, lx, lane, RPRE ? r1pre : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -178,9 +178,13 @@ def main():
         t1 = time.perf_counter()
         clipmod.run_clip(h, d_clip, n_local, kint, hint, False, st)
         dtc = time.perf_counter() - t1
-        cadence = {"value": round(n_local / dtc, 2), "unit": "frames/s", "fps": a.cadence, "keypoint_interval": kint, "homography_interval": hint,
-                   "hrnet_frames": len(st["detected_frames"]), "frames": n_local,
-                   "note": "stateful reference cadence (cm.py:205-206): detector on every frame, HRNet on hrnet_frames of them, LK flow + loop body per frame; one clip, one GPU"}
+        if world > 1:                                    # configs[4] shape: one clip per rank (the cadence is sequential within a clip), slowest rank counts
+            tc = torch.tensor([dtc], device=tdev, dtype=torch.float64)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            dtc = float(tc.item())
+        cadence = {"value": round(n_local * world / dtc, 2), "unit": "frames/s", "fps": a.cadence, "keypoint_interval": kint, "homography_interval": hint,
+                   "hrnet_frames": len(st["detected_frames"]), "frames": n_local * world, "clips": world,
+                   "note": "stateful reference cadence (cm.py:205-206): detector on every frame, HRNet on hrnet_frames of each clip's frames, LK flow + loop body per frame; one clip per GPU"}
         log(f"reference cadence @{a.cadence} fps: {cadence['value']} frames/s ({cadence['hrnet_frames']} HRNet frames)")
 
     # dominant kernel = the implicit-GEMM convolution family: per-launch HIP events on the launch stream

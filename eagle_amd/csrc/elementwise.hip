@@ -147,14 +147,17 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
 {
     constexpr int VN = Vec<T>::N;
     const int H = a.y.h, W = a.y.w, groups = a.y.c / VN;
-    const size_t total = (size_t)a.y.n * H * W * groups;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const size_t pix = i / groups;
-        const int ox = (int)(pix % W);
-        const int oy = (int)((pix / W) % H);
-        const int n = (int)(pix / ((size_t)W * H));
-        Vec<T> acc; acc.load(a.base.p, pix * a.base.cs + a.base.off + g * VN);
+    // 32-bit index arithmetic (the launcher checks that every tensor has fewer than 2^31 elements): the four divisions per item
+    // are a visible share of this kernel's instruction count in 64 bits
+    const unsigned total = (unsigned)a.y.n * H * W * groups;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int g = (int)(i % (unsigned)groups);
+        const unsigned pix = i / (unsigned)groups;
+        const int ox = (int)(pix % (unsigned)W);
+        const unsigned rowi = pix / (unsigned)W;
+        const int oy = (int)(rowi % (unsigned)H);
+        const int n = (int)(rowi / (unsigned)H);
+        Vec<T> acc; acc.load(a.base.p, (size_t)pix * a.base.cs + a.base.off + g * VN);
         for (int j = 0; j < a.n_up; ++j) {
             const TView& z = a.z[j];
             const float sh = (H > 1) ? (float)(z.h - 1) / (float)(H - 1) : 0.f;
@@ -163,12 +166,12 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
             const int y0 = (int)fy, x0 = (int)fx;
             const int y1 = y0 + (y0 < z.h - 1 ? 1 : 0), x1 = x0 + (x0 < z.w - 1 ? 1 : 0);
             const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
-            const size_t b = (size_t)n * z.h * z.w;
+            const unsigned b = (unsigned)n * z.h * z.w, co = (unsigned)(z.off + g * VN);
             Vec<T> p00, p01, p10, p11;
-            p00.load(z.p, (b + (size_t)y0 * z.w + x0) * z.cs + z.off + g * VN);
-            p01.load(z.p, (b + (size_t)y0 * z.w + x1) * z.cs + z.off + g * VN);
-            p10.load(z.p, (b + (size_t)y1 * z.w + x0) * z.cs + z.off + g * VN);
-            p11.load(z.p, (b + (size_t)y1 * z.w + x1) * z.cs + z.off + g * VN);
+            p00.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x0) * (unsigned)z.cs + co));
+            p01.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x1) * (unsigned)z.cs + co));
+            p10.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x0) * (unsigned)z.cs + co));
+            p11.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x1) * (unsigned)z.cs + co));
 #pragma unroll
             for (int k = 0; k < VN; ++k) {
                 const float top = fmaf(lx1, p01.v[k], lx0 * p00.v[k]);
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
         if (a.relu)
 #pragma unroll
             for (int k = 0; k < VN; ++k) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : 0.f;
-        acc.store(a.y.p, pix * a.y.cs + a.y.off + g * VN);
+        acc.store(a.y.p, (size_t)pix * a.y.cs + a.y.off + g * VN);
     }
 }
 
@@ -191,6 +194,9 @@ void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, c
     for (int i = 0; i < n_up; ++i) a.z[i] = ups[i].z;
     const int vn = y.f32 ? 4 : 8;
     const size_t total = (size_t)y.n * y.h * y.w * (y.c / vn);
+    size_t biggest = (size_t)y.n * y.h * y.w * std::max(y.cs, base.cs);
+    for (int i = 0; i < n_up; ++i) biggest = std::max(biggest, (size_t)ups[i].z.n * ups[i].z.h * ups[i].z.w * ups[i].z.cs);
+    if (biggest >= ((size_t)1 << 31)) fail(EAGLE_E_INVALID, "fuse: a tensor of %d frames reaches 2^31 elements; use a smaller device batch", y.n);
     if (y.f32) hipLaunchKernelGGL(fuse_sum_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(fuse_sum_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());

@@ -1114,7 +1114,9 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     }
     a.gy = gy;
     static const int xcd_env = getenv("EAGLE_CONV_XCD") ? atoi(getenv("EAGLE_CONV_XCD")) : 1;
-    a.xcd = (precision == EAGLE_PREC_F16 && c.variant != 1 && c.variant != 5 && !conv_ws(c) && c.ks == 3 && xcd_env) ? 1 : 0;
+    // 1x1 layers with several Cout blocks re-read their input tile once per block: in tile-major / block-minor order on one XCD the
+    // re-reads hit that XCD's L2 instead of HBM
+    a.xcd = (precision == EAGLE_PREC_F16 && c.variant != 1 && c.variant != 5 && !conv_ws(c) && (c.ks == 3 || (c.ks == 1 && gy > 1)) && xcd_env) ? 1 : 0;
     dim3 grid(gx, gy);
     if (a.xcd) grid = dim3(gx * gy, 1);
     if (dma || conv_ws(c)) grid = dim3(gx, 1);

@@ -32,11 +32,15 @@ def main(argv=None):
     ap.add_argument("--num-keypoint-detection", type=int, default=3, help="key-point model runs per second (main.py:27: 3)")
     ap.add_argument("--every-frame", action="store_true", help="key-points and homography on every frame (stateless configuration)")
     ap.add_argument("--calibration", action="store_true")
+    ap.add_argument("--native-fps", type=float, default=None, help="frame rate of --clip: sample it down to --fps the way read_video does (io.py:17-25)")
     a = ap.parse_args(argv)
 
     from . import synth
     from .coordinate_model import CoordinateModel
     frames = np.load(a.clip) if a.clip else synth.clip(a.seed, a.frames)
+    if a.native_fps is not None:
+        from . import io as eio
+        frames, _ = eio.read_clip(frames, a.native_fps, a.fps)
     n, h, w, _ = frames.shape
     model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
                             precision=a.precision, device=a.device, seed=a.seed)

@@ -263,9 +263,48 @@ def dump_flow():
     json.dump(out, open(f"{HERE}/flow_golden.json", "w"))
 
 
+def dump_ingest():
+    """ingest_golden.json: the reference's own read_video (eagle/utils/io.py:5-27) over a stubbed cv2.VideoCapture that yields the
+    frame index as the frame: which frames it keeps for a native / target frame-rate pair (pins the sampling of SURVEY §8f row 4)."""
+    cv2 = sys.modules["cv2"]
+    cv2.CAP_PROP_FPS = 5
+
+    class Cap:
+        spec = (0, 0.0)
+
+        def __init__(self, path):
+            self.n, self.fps = Cap.spec
+            self.k = 0
+
+        def get(self, prop):
+            return self.fps
+
+        def read(self):
+            if self.k >= self.n:
+                return False, None
+            self.k += 1
+            return True, self.k - 1
+
+        def release(self):
+            pass
+
+    cv2.VideoCapture = Cap
+    io = load_by_path("ref_io", f"{REF}/eagle/utils/io.py")
+    out = []
+    for n, native, fps in [(50, 25.0, 24), (50, 29.97, 24), (60, 50.0, 24), (61, 60.0, 24), (30, 59.94, 5), (10, 24.0, 5), (7, 30.0, 30), (9, 23.976, 24)]:
+        Cap.spec = (n, native)
+        try:
+            frames, _ = io.read_video(f"{REF}/main.py", fps)
+            out.append({"n": n, "native_fps": native, "fps": fps, "kept": frames, "raises": None})
+        except Exception as e:
+            out.append({"n": n, "native_fps": native, "fps": fps, "kept": None, "raises": type(e).__name__})
+    json.dump(out, open(f"{HERE}/ingest_golden.json", "w"))
+
+
 if __name__ == "__main__":
     dump_pitch()
     dump_hrnet()
     dump_loop()
     dump_cadence()
     dump_flow()
+    dump_ingest()

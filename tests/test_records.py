@@ -86,3 +86,23 @@ def test_process_dict_view():
     out = records.to_process_dict(_fill_record(CASES[0]))
     assert set(out) >= {"players", "ball", "H"} and out["H"].shape == (3, 3)
     assert all(v["Type"] in ("Player", "Goalkeeper") for v in out["players"].values())
+
+
+def test_ingest_sampling_equals_reference_read_video():
+    """eagle_amd/io.py against the indices the reference's own read_video kept (tests/golden/ingest_golden.json: the reference
+    function run over a stubbed cv2.VideoCapture in the build container)."""
+    import json
+    import os
+    import pytest
+    from eagle_amd import io as eio
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ingest_golden.json")))
+    for g in gold:
+        if g["raises"]:
+            with pytest.raises(Exception) as e:
+                eio.sample_indices(g["n"], g["native_fps"], g["fps"])
+            assert type(e.value).__name__ == g["raises"]
+        else:
+            assert eio.sample_indices(g["n"], g["native_fps"], g["fps"]) == g["kept"]
+    clip = np.arange(12 * 2 * 2 * 3, dtype=np.uint8).reshape(12, 2, 2, 3)
+    frames, fps = eio.read_clip(clip, 50.0, 24)
+    assert fps == 24 and frames.shape == (6, 2, 2, 3) and np.array_equal(frames, clip[::2])

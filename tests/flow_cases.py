@@ -22,6 +22,13 @@ CLIPS = {
     "blackout": (8, 2, 2, [(0, 0), (0, 2), (-1, 4), (0, 6), (0, 8), (0, 10), (-1, 12), (-1, 14), (0, 16), (0, 18)], False),
     # brightness calibration on
     "calib": (6, 1, 2, [(4, 3 * i) for i in range(7)], True),
+    # a dark key-point on the image's first column: the reference indexes a 3-column grid at [3, 3] and raises IndexError (cm.py:545)
+    "calib_edge": (6, 1, 2, [(4, 3 * i) for i in range(3)], True),
+    # one-frame clip; a clip shorter than the key-point interval
+    "single": (25, 1, 3, [(0, 0)], False),
+    "short": (25, 1, 3, [(0, 2 * i) for i in range(3)], False),
+    # no frame ever detects 4 key-points: the forward search runs off the end (cm.py:291-299), every later frame detects on demand
+    "never4": (6, 1, 2, [(1, 2 * i) for i in range(5)], False),
 }
 
 
@@ -53,6 +60,10 @@ def canned(name):
             kp = kp[:2]
         if name == "blackout" and i in (6, 7):
             kp = kp[:3]
+        if name == "never4":
+            kp = kp[:3]
+        if name == "calib_edge" and i == 0:
+            kp = kp + [(56 if all(t[0] != 56 for t in kp) else 55, 0.0, 0.5, 0.9)]
         nd = int(rng.integers(0, 30))
         d = np.zeros((nd, 6), np.float32)
         d[:, 0] = rng.uniform(-5, 1250, nd); d[:, 1] = rng.uniform(-5, 690, nd)

@@ -322,6 +322,7 @@ struct HomoShared {
     unsigned char mask[EAGLE_MAX_KP];
     int niters, max_good, ok, stop, iter, fail_run, ni;
     int pos, natt, newpos;             // cursor into the precomputed MWC stream; attempts parsed this round
+    unsigned char draw[RANSAC_WIN + 256];   // the round's slice of the random stream, already reduced modulo the point count
     unsigned tuple[RANSAC_WIN];        // 4 packed point indices of the sampling attempt starting at window position w
     unsigned char len[RANSAC_WIN];     // draws it consumes (0 = stream exhausted)
     int start[POST_T];
@@ -411,15 +412,26 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
         return;
     }
     const float t2 = (float)(thresh * thresh);
+#ifdef EAGLE_DEBUG_RANSAC
+    long long tA = 0, tB = 0, tC = 0, tD = 0, t0_ = wall_clock64(); int rounds_ = 0;
+#define RT(acc_) { const long long now_ = wall_clock64(); acc_ += now_ - t0_; t0_ = now_; }
+#else
+#define RT(acc_)
+#endif
     for (;;) {
         if (S.stop || S.iter >= S.niters) break;       // uniform: shared values, read after a barrier
         // (a) every window position: the sampling attempt that would start at that draw (getSubset's inner loops:
         //     draw until 4 distinct indices), its packed indices and the number of draws it consumes
+        for (int e = tid; e < RANSAC_WIN + 256; e += POST_T) {      // one coalesced pass over the stream, one modulo per draw
+            const int j = S.pos + e;
+            S.draw[e] = j < RNG_N ? (unsigned char)(rng_raw[j] % (unsigned)n) : (unsigned char)0;
+        }
+        __syncthreads();
         for (int w = tid; w < RANSAC_WIN; w += POST_T) {
             int j = S.pos + w, cnt = 0, idx[4] = {0, 0, 0, 0};
             const int j0 = j;
             while (cnt < 4 && j < RNG_N && j - j0 < 250) {
-                const int v = (int)(rng_raw[j++] % (unsigned)n);
+                const int v = (int)S.draw[j++ - S.pos];
                 bool dup = false;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dup = dup || (q < cnt && idx[q] == v);
@@ -433,12 +445,29 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
             S.tuple[w] = (unsigned)idx[0] | ((unsigned)idx[1] << 8) | ((unsigned)idx[2] << 16) | ((unsigned)idx[3] << 24);
         }
         __syncthreads();
-        if (tid == 0) {                               // (b) hop chain: attempt k starts where attempt k-1 stopped drawing
+        RT(tA)
+        if (tid < 64) {                               // (b) hop chain: attempt k starts where attempt k-1 stopped drawing
+            // Sequential by nature, but almost every attempt consumes exactly 4 draws (no repeated index): one wave guesses that the
+            // next 64 attempts do, checks all of them at once, accepts the run up to the first one that does not, and restarts behind it.
             int p = 0, k = 0;
-            while (k < POST_T && p < RANSAC_WIN && S.len[p] > 0) { S.start[k++] = p; p += S.len[p]; }
-            S.natt = k; S.newpos = S.pos + p;
+            for (;;) {
+                const int room = POST_T - k;
+                if (room <= 0 || p >= RANSAC_WIN) break;
+                const int q = p + 4 * tid;
+                const int len = (tid < room && q < RANSAC_WIN) ? (int)S.len[q] : 0;
+                const unsigned long long bad = __ballot(len != 4);
+                const int f = bad ? __ffsll((long long)bad) - 1 : 64;       // lanes below f start where the guess says
+                if (tid < f) S.start[k + tid] = q;
+                if (f == 64) { k += 64; p += 256; continue; }
+                const int lf = __shfl(len, f), qf = __shfl(q, f);
+                if (lf <= 0) { k += f; p = qf; break; }                  // stream exhausted / beyond the window / no room: stop in front of it
+                if (tid == 0) S.start[k + f] = qf;
+                k += f + 1; p = qf + lf;
+            }
+            if (tid == 0) { S.natt = k; S.newpos = S.pos + p; }
         }
         __syncthreads();
+        RT(tB)
         if (tid < S.natt) {                           // (c) degeneracy test, 4-point model and its support, in parallel
             const unsigned tp = S.tuple[S.start[tid]];
             const int idx[4] = {(int)(tp & 255), (int)((tp >> 8) & 255), (int)((tp >> 16) & 255), (int)(tp >> 24)};
@@ -459,6 +488,7 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
             S.code[tid] = 255;
         }
         __syncthreads();
+        RT(tC)
         if (tid == 0) {                               // (d) replay the attempts in order = the sequential RANSAC loop
             int iter = S.iter, fail_run = S.fail_run, niters = S.niters, max_good = S.max_good, stop = 0;
             const int natt = S.natt;
@@ -466,6 +496,33 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
             for (int c16 = 0; c16 * 16 < natt && !stop && iter < niters; ++c16) {
                 const uint4 pk = *(const uint4*)&S.code[c16 * 16];
                 const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+                {   // 16 attempts at once when none of them can change the state beyond counters: no new best (every inlier count, i.e. every
+                    // byte below 128, is <= the running best), the iteration bound is not reached inside the chunk, no 1000-failure stop
+                    unsigned m255[4], improv = 0; int n255 = 0;
+                    const int thr = max_good > 3 ? max_good : 3;
+                    const unsigned add = (unsigned)(127 - thr) * 0x01010101u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        m255[j] = ((wds[j] & 0x7F7F7F7Fu) + 0x01010101u) & wds[j] & 0x80808080u;       // bit 7 of a byte: the byte is 255
+                        n255 += __popc(m255[j]);
+                        improv |= ((wds[j] & 0x7F7F7F7Fu) + add) & 0x80808080u & ~wds[j];
+                    }
+                    const int nvalid = 16 - n255;
+                    if (c16 * 16 + 16 <= natt && thr <= 127 && !improv && iter + nvalid < niters && fail_run + 16 < 1000) {
+                        iter += nvalid;
+                        if (nvalid == 0) fail_run += 16;
+                        else {
+                            int last = 0;                                 // index of the last attempt of the chunk that is not a degenerate subset
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned nm = ~m255[j] & 0x80808080u;
+                                if (nm) last = j * 4 + ((31 - __clz((int)nm)) >> 3);
+                            }
+                            fail_run = 15 - last;
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
                     const int k = c16 * 16 + b;
@@ -489,8 +546,15 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
             S.iter = iter; S.fail_run = fail_run; S.pos = S.newpos;
         }
         __syncthreads();
+        RT(tD)
+#ifdef EAGLE_DEBUG_RANSAC
+        ++rounds_;
+#endif
     }
     __syncthreads();
+#ifdef EAGLE_DEBUG_RANSAC
+    if (tid == 0) printf("ransac: rounds %d iter %d  parse %.1f us  hop %.1f us  models %.1f us  replay %.1f us (100 MHz ticks)\n", rounds_, S.iter, tA * 0.01, tB * 0.01, tC * 0.01, tD * 0.01);
+#endif
     if (S.max_good <= 0) return;                      // S.ok == 0
     for (int i = tid; i < n; i += POST_T) S.mask[i] = reproj_err1(S.src, S.dst, i, S.best) <= t2;
     __syncthreads();

@@ -732,19 +732,26 @@ __device__ void synthesize_block(SynthShared& Y, EagleKeypoint* kp, int* nkp_io,
         Y.cok[c] = ok;
     }
     __syncthreads();
-    if (tid == 0) {
-        int nkp = nkp0, added = 0;
-        for (int c = 0; c < PT_NY * PT_NX && added < 30; ++c) {
-            if (!Y.cok[c]) continue;
-            const int lab = PT_CROSS[c / PT_NX][c % PT_NX];
-            if (Y.slot_of[lab] >= 0) continue;
-            EagleKeypoint e; e.label = lab; e.x = Y.cx[c]; e.y = Y.cy[c]; e.score = 0.f;
-            e.synthesized = 1; e.on_plane = 0; e.inlier = 0; e.pad = 0;
-            Y.slot_of[lab] = (signed char)nkp;
-            kp[nkp++] = e;
-            ++added;
+    if (tid < 64) {                                      // one wave walks the candidates in order, 64 at a time through a ballot
+        int nkp = nkp0, added = 0;                       // (every lane keeps the same counters; lane 0 writes)
+        for (int base = 0; base < PT_NY * PT_NX && added < 30; base += 64) {
+            const int c = base + tid;
+            unsigned long long m = __ballot(c < PT_NY * PT_NX && Y.cok[c] != 0);
+            while (m && added < 30) {
+                const int cc = base + __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int lab = PT_CROSS[cc / PT_NX][cc % PT_NX];
+                if (Y.slot_of[lab] >= 0) continue;       // written by lane 0 below; LDS operations of one wave execute in order
+                if (tid == 0) {
+                    EagleKeypoint e; e.label = lab; e.x = Y.cx[cc]; e.y = Y.cy[cc]; e.score = 0.f;
+                    e.synthesized = 1; e.on_plane = 0; e.inlier = 0; e.pad = 0;
+                    Y.slot_of[lab] = (signed char)nkp;
+                    kp[nkp] = e;
+                }
+                ++nkp; ++added;
+            }
         }
-        *nkp_io = nkp;
+        if (tid == 0) *nkp_io = nkp;
     }
     __syncthreads();
 }
@@ -998,6 +1005,12 @@ __global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
     EagleFrameResult* R = a.recs + i;
     const uint8_t* frame = a.cv.bgr + (size_t)i * a.cv.h * a.cv.w * 3;
     const bool have_flow = st->lk_valid != 0;
+#ifdef EAGLE_DEBUG_CHAIN
+    long long tq[8]; int nq = 0; tq[nq++] = wall_clock64();
+#define CT() tq[nq++] = wall_clock64();
+#else
+#define CT()
+#endif
     // mem[i] -> LDS (one entry per thread)
     const int Mn = a.mem[i].n;
     if (tid < Mn) {
@@ -1008,6 +1021,7 @@ __global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
     }
     if (have_flow) flow_filter_block(C.F, st, frame, a.cv.h, a.cv.w, tid);
     else __syncthreads();
+    CT()
     if (tid == 0) {
         // key-points of this frame (cm.py:282-324)
         const int nm = Mn > 0 ? Mn : 0;
@@ -1038,7 +1052,9 @@ __global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
     }
     __syncthreads();
     if (C.stop) return;
+    CT()
     synthesize_block(S.syn, S.kp, &S.nkp, tid);                      // cm.py:325-326
+    CT()
     if (tid == 0) {
         int stop = 0;
         if (a.calib && !calibrate_keypoints(S.kp, S.nkp, frame, a.cv.h, a.cv.w)) { st->error = 1 + i; stop = 2; }
@@ -1053,10 +1069,12 @@ __global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
     const int nkp = S.nkp;
     if (tid == 0) st->n_prev = nkp;                                  // prev_keypoints = keypoints (cm.py:329)
     if (tid < nkp) { EagleFlowKp e; e.label = S.kp[tid].label; e.x = S.kp[tid].x; e.y = S.kp[tid].y; e.score = S.kp[tid].score; st->prev[tid] = e; }
+    CT()
     if (C.attempt) {
         find_homography_block(S.hs, a.rng_raw, S.img, S.world, S.npts, pp.ransac_thresh, pp.ransac_max_iters, pp.lm_iters);
         __syncthreads();
     }
+    CT()
     if (tid == 0) {
         int own = 0;
         if (C.attempt) {
@@ -1083,6 +1101,11 @@ __global__ __launch_bounds__(POST_T) void chain_kernel(ChainArgs a)
     __syncthreads();
     for (int k = tid; k < S.nkp; k += POST_T) R->kp[k] = S.kp[k];
     project_detections(R, S.H, S.H_ok != 0, tid);
+#ifdef EAGLE_DEBUG_CHAIN
+    CT()
+    if (tid == 0 && (i == 3 || i == 25)) printf("chain frame %d: flow-filter %.1f  merge %.1f  synth %.1f  calib/select %.1f  H %.1f  record %.1f us\n", i,
+        (tq[1]-tq[0])*0.01, (tq[2]-tq[1])*0.01, (tq[3]-tq[2])*0.01, (tq[4]-tq[3])*0.01, (tq[5]-tq[4])*0.01, (tq[6]-tq[5])*0.01);
+#endif
 }
 
 // operator form of calculate_optical_flow's filter stage

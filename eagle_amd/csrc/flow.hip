@@ -77,13 +77,16 @@ void gray_pyramid_launch(const uint8_t* d_bgr, int n, int h, int w, uint8_t* g0,
 struct LkImg { const uint8_t* p; int h, w; };
 __device__ __forceinline__ int lk_px(const LkImg& im, int y, int x) { return im.p[(size_t)reflect101(y, im.h) * im.w + reflect101(x, im.w)]; }
 
-// exact workgroup sum of up to three int64 values per thread (4 waves); every thread receives the totals
+// exact workgroup sum of three values per thread (4 waves); every thread receives the totals.  A wave's partial sums fit 32 bits
+// (|diff * derivative| <= 8160 * 4080 per pixel, 64 pixels per wave: 2.13e9 < 2^31), so the cross-lane steps move 32-bit values and
+// only the four per-wave partials are added in 64 bits.
 __device__ __forceinline__ void block_sum3(long long& a, long long& b, long long& c, long long (*red)[3], int tid)
 {
+    int a32 = (int)a, b32 = (int)b, c32 = (int)c;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
+    for (int o = 32; o > 0; o >>= 1) { a32 += __shfl_down(a32, o); b32 += __shfl_down(b32, o); c32 += __shfl_down(c32, o); }
     __syncthreads();                                     // the previous round's readers are done with `red`
-    if ((tid & 63) == 0) { red[tid >> 6][0] = a; red[tid >> 6][1] = b; red[tid >> 6][2] = c; }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = a32; red[tid >> 6][1] = b32; red[tid >> 6][2] = c32; }
     __syncthreads();
     a = red[0][0] + red[1][0] + red[2][0] + red[3][0];
     b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
@@ -99,9 +102,12 @@ struct LkArgs {
     int max_count; double eps2;
 };
 
+#define LK_R 8                                   // J is cached this many pixels around the start window; beyond it the loop reads global memory
+#define LK_PJ (LK_WIN + 1 + 2 * LK_R)
 __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
 {
     __shared__ int patch[18 * 18];
+    __shared__ unsigned char jpatch[LK_PJ * LK_PJ];
     __shared__ int sdx[16 * 16], sdy[16 * 16];
     __shared__ long long red[4][3];
     ChainState* st = a.st;
@@ -153,6 +159,13 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
             const int r = e / 18, c = e - r * 18;
             patch[e] = lk_px(I, ipy - 1 + r, ipx - 1 + c);
         }
+        // ... and, in the same memory round trip, J's neighbourhood of the start window (see the iteration loop)
+        const float sx_ = nx - half, sy_ = ny - half;
+        const int jx0 = (lk_far(sx_, sy_) ? 0 : (int)floorf(sx_)) - LK_R, jy0 = (lk_far(sx_, sy_) ? 0 : (int)floorf(sy_)) - LK_R;
+        for (int e = tid; e < LK_PJ * LK_PJ; e += 256) {
+            const int r = e / LK_PJ, c = e - r * LK_PJ;
+            jpatch[e] = (unsigned char)lk_px(J, jy0 + r, jx0 + c);
+        }
         __syncthreads();
         {   // Scharr at the 16x16 positions (ipy + r, ipx + c); zero outside the image (derivative buffer is BORDER_CONSTANT)
             const int r = tid >> 4, c = tid & 15;
@@ -194,6 +207,8 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
         }
         D = 1.f / D;
         nx -= half; ny -= half;
+        // the iterations re-read the 16x16 neighbourhood of a window that moves by a fraction of a pixel to a few pixels: J's
+        // neighbourhood of the start window is in LDS (one global round trip per level instead of one per iteration)
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
@@ -209,7 +224,15 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a)
             long long sb1 = 0, sb2 = 0, dummy = 0;
             if (inwin) {
                 const int yy = iny + wy, xx = inx + wx;
-                const int diff = LK_DESCALE(lk_px(J, yy, xx) * iw00 + lk_px(J, yy, xx + 1) * iw01 + lk_px(J, yy + 1, xx) * iw10 + lk_px(J, yy + 1, xx + 1) * iw11, LK_WBITS - 5) - ival;
+                int j00, j01, j10, j11;
+                const int ry = iny - jy0, rx = inx - jx0;                 // uniform: the whole window is inside the cached patch or not
+                if (ry >= 0 && rx >= 0 && ry + LK_WIN < LK_PJ && rx + LK_WIN < LK_PJ) {
+                    const unsigned char* q = jpatch + (ry + wy) * LK_PJ + rx + wx;
+                    j00 = q[0]; j01 = q[1]; j10 = q[LK_PJ]; j11 = q[LK_PJ + 1];
+                } else {
+                    j00 = lk_px(J, yy, xx); j01 = lk_px(J, yy, xx + 1); j10 = lk_px(J, yy + 1, xx); j11 = lk_px(J, yy + 1, xx + 1);
+                }
+                const int diff = LK_DESCALE(j00 * iw00 + j01 * iw01 + j10 * iw10 + j11 * iw11, LK_WBITS - 5) - ival;
                 sb1 = (long long)diff * ixval; sb2 = (long long)diff * iyval;
             }
             block_sum3(sb1, sb2, dummy, red, tid);

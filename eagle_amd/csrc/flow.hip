@@ -83,10 +83,20 @@ __device__ __forceinline__ int lk_px(const LkImg& im, int y, int x) { return im.
 __device__ __forceinline__ void block_sum3(long long& a, long long& b, long long& c, long long (*red)[3], int tid)
 {
     int a32 = (int)a, b32 = (int)b, c32 = (int)c;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a32 += __shfl_down(a32, o); b32 += __shfl_down(b32, o); c32 += __shfl_down(c32, o); }
+    // wave reduction on the DPP path (row shifts inside 16 lanes, then row broadcasts): the total ends up in lane 63
+#define LK_DPP_STEP(CTRL_, ROWM_, BANKM_)                                                \
+    a32 += __builtin_amdgcn_update_dpp(0, a32, CTRL_, ROWM_, BANKM_, false);              \
+    b32 += __builtin_amdgcn_update_dpp(0, b32, CTRL_, ROWM_, BANKM_, false);              \
+    c32 += __builtin_amdgcn_update_dpp(0, c32, CTRL_, ROWM_, BANKM_, false);
+    LK_DPP_STEP(0x111, 0xf, 0xf)                         // row_shr:1
+    LK_DPP_STEP(0x112, 0xf, 0xf)                         // row_shr:2
+    LK_DPP_STEP(0x114, 0xf, 0xe)                         // row_shr:4
+    LK_DPP_STEP(0x118, 0xf, 0xc)                         // row_shr:8
+    LK_DPP_STEP(0x142, 0xa, 0xf)                         // row_bcast:15
+    LK_DPP_STEP(0x143, 0xc, 0xf)                         // row_bcast:31
+#undef LK_DPP_STEP
     __syncthreads();                                     // the previous round's readers are done with `red`
-    if ((tid & 63) == 0) { red[tid >> 6][0] = a32; red[tid >> 6][1] = b32; red[tid >> 6][2] = c32; }
+    if ((tid & 63) == 63) { red[tid >> 6][0] = a32; red[tid >> 6][1] = b32; red[tid >> 6][2] = c32; }
     __syncthreads();
     a = red[0][0] + red[1][0] + red[2][0] + red[3][0];
     b = red[0][1] + red[1][1] + red[2][1] + red[3][1];

@@ -124,7 +124,8 @@ struct EagleHandle {
         ChainState* h_st = nullptr;        // pinned staging of eagle_clip_flow
         ChainState* h_zero = nullptr;      // pinned: the initial loop state
         int* h_tail = nullptr;             // pinned: {stalled, error} read-back, [2] = the constant -1
-        hipEvent_t ev_gray = nullptr, ev_det = nullptr, ev_kp = nullptr;
+        MemList* h_mem = nullptr;          // pinned staging of eagle_clip_get/set_keypoints
+        hipEvent_t ev_gray = nullptr, ev_det = nullptr, ev_kp = nullptr, ev_loop = nullptr;
     } clip;
     // comm
     void* rccl = nullptr; void* comm = nullptr; int rank = 0, world = 1;
@@ -606,7 +607,8 @@ static void clip_close(EagleHandle* h)
     if (c.h_st) (void)hipHostFree(c.h_st);
     if (c.h_zero) (void)hipHostFree(c.h_zero);
     if (c.h_tail) (void)hipHostFree(c.h_tail);
-    for (hipEvent_t e : {c.ev_gray, c.ev_det, c.ev_kp}) if (e) (void)hipEventDestroy(e);
+    if (c.h_mem) (void)hipHostFree(c.h_mem);
+    for (hipEvent_t e : {c.ev_gray, c.ev_det, c.ev_kp, c.ev_loop}) if (e) (void)hipEventDestroy(e);
     c = EagleHandle::Clip();
 }
 
@@ -635,10 +637,11 @@ static void clip_open(EagleHandle* h, const uint8_t* d_bgr, int n)
     HIP_CHECK(hipHostMalloc((void**)&c.h_st, sizeof(ChainState), hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void**)&c.h_zero, sizeof(ChainState), hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void**)&c.h_tail, sizeof(int) * 4, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&c.h_mem, sizeof(MemList), hipHostMallocDefault));
     memset(c.h_zero, 0, sizeof(ChainState));
     c.h_zero->stalled = -1;
     c.h_tail[0] = -1; c.h_tail[1] = 0; c.h_tail[2] = -1;
-    for (hipEvent_t* e : {&c.ev_gray, &c.ev_det, &c.ev_kp}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&c.ev_gray, &c.ev_det, &c.ev_kp, &c.ev_loop}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     HIP_CHECK(hipMemsetAsync(c.mem, 0xFF, sizeof(MemList) * nn, h->s_main));                  // n = -1 everywhere
     HIP_CHECK(hipMemsetAsync(c.recs, 0, sizeof(EagleFrameResult) * nn, h->s_main));
     HIP_CHECK(hipMemcpyAsync(c.st, c.h_zero, sizeof(ChainState), hipMemcpyHostToDevice, h->s_main));
@@ -647,6 +650,7 @@ static void clip_open(EagleHandle* h, const uint8_t* d_bgr, int n)
     HIP_CHECK(hipStreamWaitEvent(h->s_det, c.ev_gray, 0));       // the record memset precedes the first detector write
     HIP_CHECK(hipEventRecord(c.ev_det, h->s_det));
     HIP_CHECK(hipEventRecord(c.ev_kp, h->s_main));
+    HIP_CHECK(hipEventRecord(c.ev_loop, h->s_post));
 }
 
 // detector + decode + NMS + object rules of frames [first, first+count) (cm.py:331 detect_objects), records kept in HBM; asynchronous
@@ -659,6 +663,10 @@ static void clip_detect_objects(EagleHandle* h, int first, int count)
     size_t ev_i = 0;
     EagleHandle::StepBuf& sb = h->sb[0];
     const bool prof = h->prof; h->prof = false;
+    // The network passes do NOT run under the sequential loop of earlier frames: with them overlapped the LK results of the running
+    // loop were not reproducible (1-pixel differences on a few frames per clip, never with the loop alone on the GPU; cause not yet
+    // found).  Until it is, a pass waits for the loop enqueued so far.
+    HIP_CHECK(hipStreamWaitEvent(h->s_det, c.ev_loop, 0));
     for (int i = first; i < first + count; i += B) {
         const int na = std::min(B, first + count - i);
         HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_det));
@@ -682,6 +690,7 @@ static void clip_detect_keypoints(EagleHandle* h, int first, int stride, int cou
     size_t ev_i = 0;
     EagleHandle::StepBuf& sb = h->sb[0];
     const bool prof = h->prof; h->prof = false;
+    HIP_CHECK(hipStreamWaitEvent(h->s_main, c.ev_loop, 0));     // see clip_detect_objects
     for (int k0 = 0; k0 < count; k0 += B) {
         const int na = std::min(B, count - k0);
         const uint8_t* src;
@@ -972,9 +981,10 @@ int eagle_clip_get_keypoints(EagleHandle* h, int frame, EagleFlowKp* out, int* n
     CLIP_CHECK(h, h->clip.open && frame >= 0 && frame < h->clip.cv.n && out && n, "eagle_clip_get_keypoints: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
+    eagle::clip_sync(h);                                  // host access to mem[]: nothing of the session is in flight (see clip_detect_objects)
+    MemList& m = *h->clip.h_mem;
+    HIP_CHECK(hipMemcpyAsync(&m, h->clip.mem + frame, sizeof(m), hipMemcpyDeviceToHost, h->s_main));
     HIP_CHECK(hipStreamSynchronize(h->s_main));
-    MemList m;
-    HIP_CHECK(hipMemcpy(&m, h->clip.mem + frame, sizeof(m), hipMemcpyDeviceToHost));
     *n = m.n;
     for (int k = 0; k < m.n && k < EAGLE_N_LANDMARKS; ++k) out[k] = m.kp[k];
     API_END(h)
@@ -986,11 +996,14 @@ int eagle_clip_set_keypoints(EagleHandle* h, int frame, const EagleFlowKp* in, i
                "eagle_clip_set_keypoints: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
-    HIP_CHECK(hipStreamSynchronize(h->s_main));
-    MemList m; memset(&m, 0, sizeof(m));
+    eagle::clip_sync(h);
+    MemList& m = *h->clip.h_mem;
+    memset(&m, 0, sizeof(m));
     m.n = n;
     for (int k = 0; k < n; ++k) m.kp[k] = in[k];
-    HIP_CHECK(hipMemcpy(h->clip.mem + frame, &m, sizeof(m), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpyAsync(h->clip.mem + frame, &m, sizeof(m), hipMemcpyHostToDevice, h->s_main));
+    HIP_CHECK(hipEventRecord(h->clip.ev_kp, h->s_main));      // eagle_clip_run orders the loop behind this write
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
     API_END(h)
 }
 
@@ -1005,6 +1018,7 @@ int eagle_clip_flow(EagleHandle* h, int src_frame, int dst_frame, int hue_frame,
     EagleHandle::Clip& c = h->clip;
     *n_out = 0;
     if (n_in == 0) return EAGLE_OK;                       // cm.py:429: empty dict in -> empty dict out
+    eagle::clip_sync(h);                                  // the operator runs alone on the GPU (see clip_detect_objects)
     ChainState& z = *c.h_st;
     memset(&z, 0, sizeof(z));
     z.stalled = -1; z.n_prev = n_in;
@@ -1034,12 +1048,14 @@ int eagle_clip_run(EagleHandle* h, int first, int last, int keypoint_interval, i
     HIP_CHECK(hipStreamWaitEvent(sp, c.ev_kp, 0));
     if (first < last) {
         if (first == 0) HIP_CHECK(hipMemcpyAsync(c.st, c.h_zero, sizeof(ChainState), hipMemcpyHostToDevice, sp));
-        else HIP_CHECK(hipMemcpyAsync((char*)c.st + offsetof(ChainState, stalled), &c.h_tail[2], sizeof(int), hipMemcpyHostToDevice, sp));   // resume
+        else if (wait) HIP_CHECK(hipMemcpyAsync((char*)c.st + offsetof(ChainState, stalled), &c.h_tail[2], sizeof(int), hipMemcpyHostToDevice, sp));   // resume
+        // (an asynchronous call for a later chunk must NOT clear the flag: if an earlier chunk stalled, its launches have to fall through too)
     }
     for (int i = first; i < last; ++i) {
         lk_launch(c.cv, i > 0 ? i - 1 : 0, i, c.st, c.mem, keypoint_interval, sp);
         chain_launch(c.cv, c.st, c.mem, c.recs, h->pp, i, keypoint_interval, homography_interval, calibration, sp);
     }
+    HIP_CHECK(hipEventRecord(c.ev_loop, sp));
     if (stalled_at) *stalled_at = -1;
     if (wait) {
         HIP_CHECK(hipMemcpyAsync(c.h_tail, (char*)c.st + offsetof(ChainState, stalled), sizeof(int) * 2, hipMemcpyDeviceToHost, sp));

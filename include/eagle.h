@@ -147,7 +147,8 @@ int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double*
  *   eagle_clip_run              the loop body for frames [first, last), in order, on the GPU without host round trips, on its own
  *                               stream behind every pass enqueued so far (so the passes of later frames overlap it); it stops itself
  *                               at a frame that needs a model detection it does not have.  wait = 1: block and report that frame
- *                               (*stalled_at, else -1); first > 0 resumes the loop state of the previous call
+ *                               (*stalled_at, else -1); first > 0 continues with the loop state of the previous call, and with wait = 1 it
+ *                               is the resume after an on-demand detection (clears the stall mark first)
  *   eagle_clip_fetch            the n records.  EagleFrameResult.pad[0] = 1 when the frame solved its own homography
  *                               ("Keypoints" = its inliers, cm.py:359-362); kp[].pad bit 0: the value came from the flow, bit 1: moved by the calibration
  *                               (both are numpy integers in the reference's dict, which json.dump(default=float) writes as floats). */

@@ -106,6 +106,34 @@ def test_loop_with_replayed_detections_equals_reference_loop(model, name):
         assert got["Boundaries"] == ref["Boundaries"] and got["Time"] == ref["Time"], (name, i)
 
 
+@pytest.mark.parametrize("name", ["blackout", "fps25", "late_start"])
+def test_loop_in_several_chunks_equals_reference_loop(name):
+    """Device batch 2 -> chunks of 2 * keypoint_interval frames: the loop of a later chunk is enqueued while an earlier chunk may have
+    stopped at a frame that needs an on-demand detection; it must fall through, and the resume must pick up exactly there."""
+    fps, nh, nk, spec, calib = flow_cases.CLIPS[name]
+    frames = np.stack(flow_cases.frames_of(name))
+    kps, _ = flow_cases.canned(name)
+    hgt, wid = frames[0].shape[:2]
+
+    def source(i):
+        dec = [t for t in kps[i] if t[3] > 0.01]
+        return to_flowkp(host.keypoints_from_decoded(dec, hgt, wid, 0.3), {INTERSECTION_TO_PITCH_POINTS[t[0]]: t[3] for t in dec})
+
+    m = CoordinateModel(precision="f16", batch=2)
+    try:
+        stats = {}
+        recs = m.flow_records(frames, max(1, int(fps / max(1, nk))), max(1, int(fps / max(1, nh))), calib, stats=stats, keypoint_source=source)
+    finally:
+        m.handle.close()
+    gold = GOLD[name]
+    assert stats["detected_frames"] == gold["detected_frames"]
+    for i, r in enumerate(recs):
+        got = _norm(records.to_reference_dict(r, i, fps, own_h=bool(r["pad"][0])))
+        ref = gold["records"][str(i)]
+        assert got["Keypoints"] == ref["Keypoints"] and list(got["Keypoints"]) == list(ref["Keypoints"]), (name, i)
+        assert got["Boundaries"] == ref["Boundaries"], (name, i)
+
+
 def test_loop_with_real_networks_equals_oracle_loop():
     """fp32 family end to end: HRNet / YOLOv8 detections come from the stateless path, the oracle's loop restatement consumes
     them, and the clip session (which runs the same networks itself, on the cadence's frames only) must agree record by record."""

@@ -3,8 +3,8 @@ keypoint_interval > 1 and/or calibration) over the clip session of the C ABI (in
 
 What runs where: the gray pyramids of all frames; per chunk of frames the detector on every frame and HRNet on every
 keypoint_interval-th frame, in batches, on two streams; and on a third stream ONE pyramidal-LK launch and ONE loop-body launch per
-frame, stream-ordered, without host round trips — the network passes of chunk c+1 overlap the sequential loop of chunk c.  The
-host steps in only where the reference itself leaves its cadence: the first-frame search (cm.py:289-311) and on-demand detections
+frame, stream-ordered, without host round trips.  (The library currently makes the network passes of chunk c+1 wait for the loop
+of chunk c: overlapped, the loop's LK results were not reproducible — DESIGN.md §8c, open issue.)  The host steps in only where the reference itself leaves its cadence: the first-frame search (cm.py:289-311) and on-demand detections
 (cm.py:317), after which the loop resumes at the frame that asked."""
 import numpy as np
 
@@ -29,7 +29,7 @@ def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=Fal
     try:
         h.clip_open(dptr, n)
         # chunks of batch * keypoint_interval frames: one full HRNet batch of scheduled frames per chunk.  Everything below is
-        # enqueued asynchronously: the detector / HRNet passes of chunk c+1 run under the sequential loop of chunk c.
+        # enqueued asynchronously; the detector and HRNet passes of a chunk run concurrently with each other.
         chunk = max(1, int(h.cfg.batch)) * keypoint_interval
         for c0 in range(0, n, chunk):
             c1 = min(n, c0 + chunk)

@@ -1,0 +1,51 @@
+"""Developer probe for the open issue of DESIGN.md §8c: is eagle_clip_flow (K12 + filter) reproducible while ANOTHER handle keeps
+the GPU busy with the stateless path?  Two handles, two threads (ctypes releases the GIL)."""
+import sys, threading, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import flow_cases
+from eagle_amd import lib, synth
+from eagle_amd.coordinate_model import CoordinateModel
+from eagle_amd.pitch import INTERSECTION_TO_PITCH_POINTS, PITCH_POINTS_TO_INTERSECTION
+
+frames = np.stack(flow_cases.frames_of("fps25")[:8])
+B = CoordinateModel(precision="f16", batch=2)
+A = CoordinateModel(precision="f16", batch=8)
+d = B.handle.upload(frames)
+B.handle.clip_open(d, len(frames))
+vis = flow_cases.synth.visible_landmarks(2, 60)
+kps = np.zeros(len(vis), lib.FLOWKP_DTYPE)
+for k, (i, (x, y)) in enumerate(sorted(vis.items())):
+    kps[k] = (i, x, y, 0.9)
+ref = [B.handle.clip_flow(a, a + 1, a + 1, kps, raw=True) for a in range(7)]
+stop = False
+busy_frames = synth.clip(0, 8)
+def busy():
+    pts = np.random.default_rng(0).uniform(0, 700, (30, 2)).astype(np.float32)
+    wld = np.random.default_rng(1).uniform(0, 68, (30, 2)).astype(np.float32)
+    while not stop:
+        if mode == "busy":
+            A.process_records(busy_frames)
+        elif mode == "ransac":
+            lib.op_find_homography(pts, wld)              # a single-workgroup kernel plus its copies
+        else:
+            dd = A.handle.upload(busy_frames); A.handle.free(dd)   # copies only
+mode = sys.argv[1] if len(sys.argv) > 1 else "busy"
+t = threading.Thread(target=busy)
+if mode != "idle":
+    t.start(); time.sleep(0.5)
+bad = 0
+for rep in range(40):
+    for a in range(7):
+        out, nxt, st = B.handle.clip_flow(a, a + 1, a + 1, kps, raw=True)
+        e1 = not np.array_equal(nxt.view(np.uint32), ref[a][1].view(np.uint32)); e2 = not np.array_equal(st, ref[a][2]); e3 = not np.array_equal(out, ref[a][0])
+        if e1 or e2 or e3:
+            bad += 1
+            if bad <= 4:
+                w = np.nonzero((nxt != ref[a][1]).any(1))[0]
+                print("pair", a, "lk-points", e1, "status", e2, "filtered", e3, "points", w[:6], "got", nxt[w[:3]].tolist(), "ref", ref[a][1][w[:3]].tolist())
+stop = True
+if mode != "idle":
+    t.join()
+print(mode, "non-reproducible flow calls:", bad, "of", 40 * 7)
+B.handle.clip_close(); B.handle.free(d); A.handle.close(); B.handle.close()

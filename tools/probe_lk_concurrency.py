@@ -48,4 +48,6 @@ stop = True
 if mode != "idle":
     t.join()
 print(mode, "non-reproducible flow calls:", bad, "of", 40 * 7)
+after = sum(not np.array_equal(B.handle.clip_flow(a, a + 1, a + 1, kps, raw=True)[1].view(np.uint32), ref[a][1].view(np.uint32)) for a in range(7))
+print("pairs that still differ once the GPU is idle again (persistent corruption of the inputs):", after, "of 7")
 B.handle.clip_close(); B.handle.free(d); A.handle.close(); B.handle.close()

@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
         }
         // a wave in its MFMA phase outranks the co-resident workgroup's staging / epilogue instructions (measured per class, 5 alternating
         // runs: 384->384 95.8 -> 90.1 us, 192->192 88.0 -> 86.7 us with NT = 4; 96->96 with NT = 3 loses 2 %, hence the condition)
+#ifndef EAGLE_NO_SETPRIO
         if constexpr (NT >= 4) __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             half8 wa[NT], xb[PW];
@@ -339,7 +341,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
                     acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
         }
         mfma_phase_schedule<NI, NT, PW>();
+#ifndef EAGLE_NO_SETPRIO
         if constexpr (NT >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
         if (!PIPE) __syncthreads();
     }
 #undef STAGE_LOAD

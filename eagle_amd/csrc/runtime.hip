@@ -30,6 +30,7 @@ void fail(int code, const char* fmt, ...)
 }
 
 static thread_local std::string g_create_error;
+static int g_dbg_skip = 0;      // developer bisection (eagle_debug "skip"): 1 HRNet, 2 detector, 4 decode + NMS, 8 geometry kernel, 16 preprocess, 32 heat-map maxima, 64 fuse_sum / pool / upsample ops, 128 convolutions
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
@@ -474,6 +475,8 @@ static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
             continue;
         }
         hipStream_t st = (multi && op.stream > 0) ? h->s_br[op.stream - 1] : s;
+        if ((g_dbg_skip & 64) && op.kind == Op::OTHER) continue;
+        if ((g_dbg_skip & 128) && op.kind == Op::CONV) continue;
         if (h->prof && op.kind == Op::CONV) {
             HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], st));
             op.run(st);
@@ -492,19 +495,21 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     EagleHandle::StepBuf& sb = h->sb[p];
     size_t ev_i = 0;
     HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
-    preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
+    if (!(g_dbg_skip & 16)) preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
     const bool two = !h->prof;
     hipStream_t sd = two ? h->s_det : h->s_main;
     if (two) {
         HIP_CHECK(hipEventRecord(h->ev_pre, h->s_main));
         HIP_CHECK(hipStreamWaitEvent(sd, h->ev_pre, 0));
     }
-    run_net(h, h->yo.get(), sd, ev_i);                                   // detector branch
-    yolo_decode_launch(h->levels, 3, B, 5, c.detector_floor, h->ds, sd);
-    nms_launch(h->ds, B, h->pp, sb.d_out, sd);
+    if (!(g_dbg_skip & 2)) run_net(h, h->yo.get(), sd, ev_i);            // detector branch
+    if (!(g_dbg_skip & 4)) {
+        yolo_decode_launch(h->levels, 3, B, 5, c.detector_floor, h->ds, sd);
+        nms_launch(h->ds, B, h->pp, sb.d_out, sd);
+    }
     if (two) HIP_CHECK(hipEventRecord(h->ev_det, sd));
-    run_net(h, h->hr.get(), h->s_main, ev_i);                            // keypoint branch
-    heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
+    if (!(g_dbg_skip & 1)) run_net(h, h->hr.get(), h->s_main, ev_i);     // keypoint branch
+    if (!(g_dbg_skip & 32)) heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
     if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));     // join
 }
 
@@ -537,7 +542,7 @@ static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_activ
         HIP_CHECK(hipEventRecord(sb.ev_compute, h->s_main));
         HIP_CHECK(hipStreamWaitEvent(sp, sb.ev_compute, 0));
     }
-    post_launch(sb.parts, c.batch, h->pp, sb.d_out, sp);
+    if (!(g_dbg_skip & 8)) post_launch(sb.parts, c.batch, h->pp, sb.d_out, sp);
     HIP_CHECK(hipMemcpyAsync(sb.h_out, sb.d_out, sizeof(EagleFrameResult) * n_active, hipMemcpyDeviceToHost, sp));
     HIP_CHECK(hipEventRecord(sb.ev_done, sp));
 }
@@ -663,10 +668,9 @@ static void clip_detect_objects(EagleHandle* h, int first, int count)
     size_t ev_i = 0;
     EagleHandle::StepBuf& sb = h->sb[0];
     const bool prof = h->prof; h->prof = false;
-    // The network passes do NOT run under the sequential loop of earlier frames: with them overlapped the LK results of the running
-    // loop were not reproducible (1-pixel differences on a few frames per clip, never with the loop alone on the GPU; cause not yet
-    // found).  Until it is, a pass waits for the loop enqueued so far.
-    HIP_CHECK(hipStreamWaitEvent(h->s_det, c.ev_loop, 0));
+    // The passes of later chunks run under the sequential loop of earlier frames (three streams).  Round 1 had to serialise them
+    // behind the loop because K12 was not reproducible next to the convolution kernels; the cause was the packed-fp32 code hipcc's
+    // SLP vectoriser generated for K12 (Makefile), not the overlap.
     for (int i = first; i < first + count; i += B) {
         const int na = std::min(B, first + count - i);
         HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_det));
@@ -690,7 +694,6 @@ static void clip_detect_keypoints(EagleHandle* h, int first, int stride, int cou
     size_t ev_i = 0;
     EagleHandle::StepBuf& sb = h->sb[0];
     const bool prof = h->prof; h->prof = false;
-    HIP_CHECK(hipStreamWaitEvent(h->s_main, c.ev_loop, 0));     // see clip_detect_objects
     for (int k0 = 0; k0 < count; k0 += B) {
         const int na = std::min(B, count - k0);
         const uint8_t* src;
@@ -981,8 +984,7 @@ int eagle_clip_get_keypoints(EagleHandle* h, int frame, EagleFlowKp* out, int* n
     CLIP_CHECK(h, h->clip.open && frame >= 0 && frame < h->clip.cv.n && out && n, "eagle_clip_get_keypoints: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
-    eagle::clip_sync(h);                                  // host access to mem[]: nothing of the session is in flight (see clip_detect_objects)
-    MemList& m = *h->clip.h_mem;
+    MemList& m = *h->clip.h_mem;                          // mem[] is written on s_main (key-point passes, eagle_clip_set_keypoints)
     HIP_CHECK(hipMemcpyAsync(&m, h->clip.mem + frame, sizeof(m), hipMemcpyDeviceToHost, h->s_main));
     HIP_CHECK(hipStreamSynchronize(h->s_main));
     *n = m.n;
@@ -996,7 +998,8 @@ int eagle_clip_set_keypoints(EagleHandle* h, int frame, const EagleFlowKp* in, i
                "eagle_clip_set_keypoints: bad arguments")
     API_BEGIN
     HIP_CHECK(hipSetDevice(h->cfg.device));
-    eagle::clip_sync(h);
+    HIP_CHECK(hipStreamSynchronize(h->s_main));           // the staging buffer is free again
+    HIP_CHECK(hipStreamSynchronize(h->s_post));           // no loop launch still reads the old entry
     MemList& m = *h->clip.h_mem;
     memset(&m, 0, sizeof(m));
     m.n = n;
@@ -1018,8 +1021,7 @@ int eagle_clip_flow(EagleHandle* h, int src_frame, int dst_frame, int hue_frame,
     EagleHandle::Clip& c = h->clip;
     *n_out = 0;
     if (n_in == 0) return EAGLE_OK;                       // cm.py:429: empty dict in -> empty dict out
-    eagle::clip_sync(h);                                  // the operator runs alone on the GPU (see clip_detect_objects)
-    ChainState& z = *c.h_st;
+    ChainState& z = *c.h_st;                              // (stream-ordered on s_main behind the gray pyramids; independent of the loop's state)
     memset(&z, 0, sizeof(z));
     z.stalled = -1; z.n_prev = n_in;
     for (int k = 0; k < n_in; ++k) z.prev[k] = in[k];
@@ -1110,6 +1112,17 @@ int eagle_get_timings(EagleHandle* h, EagleTimings* t)
     if (!h || !t) return EAGLE_E_INVALID;
     *t = h->timings;
     return EAGLE_OK;
+}
+
+int eagle_debug(const char* key, int64_t value, void* out, int64_t out_bytes)
+{
+    EagleHandle* h = nullptr;
+    int rc = 0;
+    API_BEGIN
+    if (key && !strcmp(key, "skip")) { eagle::g_dbg_skip = (int)value; return EAGLE_OK; }
+    rc = eagle::lk_debug(key, value, out, out_bytes);
+    if (rc) return EAGLE_E_INVALID;
+    API_END(h)
 }
 
 // ---- RCCL gather (resolved lazily with dlopen so the library loads on hosts without RCCL) ------------------------

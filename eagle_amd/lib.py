@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeagle_hip.so")
+LIB_PATH = os.environ.get("EAGLE_HIP_LIB") or os.path.join(_HERE, "libeagle_hip.so")   # override: developer A/B builds only
 
 MAX_DET, N_LANDMARKS, MAX_KP = 300, 57, 87
 PREC_F16, PREC_F32 = 0, 1
@@ -93,6 +93,7 @@ def load():
     L.eagle_op_fuse_sum.argtypes = [i32, i32, fp, i32, i32, i32, i32, i32, C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, fp]
     L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
     L.eagle_op_find_homography.argtypes = [i32, fp, fp, i32, C.c_double, i32, i32, dp, u8p, C.POINTER(i32)]
+    L.eagle_debug.argtypes = [C.c_char_p, i64, vp, i64]
     _lib = L
     return L
 
@@ -102,10 +103,18 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_device_free", "eagle_device_upload", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
-           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch"]
+           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug"]
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
 E_REFERENCE_RAISES = -7
+
+
+def debug(key, value=0, out=None):
+    """Developer diagnostics (include/eagle.h, eagle_debug)."""
+    rc = load().eagle_debug(key.encode(), int(value), None if out is None else out.ctypes.data_as(C.c_void_p), 0 if out is None else out.nbytes)
+    if rc:
+        raise EagleError(f"eagle_debug({key}) failed ({rc})")
+    return out
 
 
 def abi_sizes():

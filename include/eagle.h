@@ -196,6 +196,10 @@ int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, in
 int eagle_op_find_homography(int device, const float* img_pts, const float* world_pts, int n, double thresh,
                              int max_iters, int lm_iters, double* H9, uint8_t* mask, int* ok);
 
+/* Developer diagnostics (process-wide switches and read-backs used by tools/probe_lk_concurrency.py; not part of the data path).
+ * Keys: "lk_threads" (64 | 256), "lk_dbg" (1 trace, 2 LDS guard words, 4 end-of-level verification, 8 L1-bypassing loads), "lk_excl_lds" (bytes), "lk_trace", "lk_counters". */
+int eagle_debug(const char* key, int64_t value, void* out, int64_t out_bytes);
+
 #ifdef __cplusplus
 }
 #endif

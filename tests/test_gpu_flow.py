@@ -179,3 +179,64 @@ def _oracle(frames, kint, hint, det_kp, det_obj):
     for i in res:
         res[i]["Time"] = None
     return res, st
+
+
+@pytest.mark.parametrize("force", [None, "16,1,0"])
+def test_lk_bit_exact_while_another_handle_runs_the_networks(model, force, state_dicts):
+    """K12 + filters against the oracle WHILE a second handle keeps the GPU busy with the stateless path on another thread
+    (round 1's open issue: next to the convolution kernels K12 returned different sub-pixel results — DESIGN.md §8c; the worst
+    co-runner found by tools/probe_lk_concurrency.py is the plain register-staged kernel at kc = 16, nt = 1, forced here)."""
+    import threading
+    from eagle_amd import synth
+    hs, ys = state_dicts
+    if force:
+        os.environ["EAGLE_CONV_FORCE"] = force
+    try:
+        co = CoordinateModel(precision="f16", batch=8, hrnet_state_dict=hs, detector_state_dict=ys)
+    finally:
+        os.environ.pop("EAGLE_CONV_FORCE", None)
+    h = model.handle
+    frames = np.stack(flow_cases.frames_of("fps25")[:6])
+    busy_frames = synth.clip(0, 8)
+    d = h.upload(frames)
+    stop, batches, err = [False], [0], []
+
+    def busy():
+        try:
+            ref = co.process_records(busy_frames)
+            while not stop[0]:
+                r = co.process_records(busy_frames)
+                batches[0] += 1
+                if any(r[f].tobytes() != ref[f].tobytes() for f in r.dtype.names):
+                    err.append("the co-running stateless path changed its own records")
+        except Exception as e:                       # pragma: no cover
+            err.append(repr(e))
+
+    t = threading.Thread(target=busy)
+    try:
+        h.clip_open(d, len(frames))
+        gray = [P.bgr2gray(f) for f in frames]
+        kps = {INTERSECTION_TO_PITCH_POINTS[i]: (int(x), int(y)) for i, (x, y) in sorted(flow_cases.synth.visible_landmarks(2, 60).items())}
+        pts = np.array(list(kps.values()), np.float32)
+        expected = {}
+        for a in range(5):
+            enxt, est = P.calc_optical_flow_pyr_lk(gray[a], gray[a + 1], pts)
+            expected[a] = (enxt, est[:, 0], flow.calculate_optical_flow(frames[a + 1], gray[a], kps, gray[a + 1]))
+        t.start()
+        calls = 0
+        while batches[0] < 12 and not err and calls < 20000:      # at least a dozen co-running network batches
+            for a in range(5):
+                got, nxt, st = h.clip_flow(a, a + 1, a + 1, to_flowkp(kps), raw=True)
+                enxt, est, exp = expected[a]
+                assert np.array_equal(st, est), (a, "status differs while the networks co-run")
+                assert np.array_equal(nxt[st == 1].view(np.uint32), enxt[est == 1].view(np.uint32)), (a, "LK points differ while the networks co-run")
+                assert from_flowkp(got) == {k: (int(v[0]), int(v[1])) for k, v in exp.items()} and list(from_flowkp(got)) == list(exp), a
+                calls += 1
+        assert not err, err
+        assert batches[0] >= 12 and calls >= 50
+    finally:
+        stop[0] = True
+        if t.is_alive():
+            t.join()
+        h.clip_close(); h.free(d)
+        co.handle.close()

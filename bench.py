@@ -10,7 +10,14 @@ Multi-GPU (driver launches one rank per GPU through torch.distributed.run): fram
 weights replicated, no data-path collective; ONE all-gather of the fixed-size records at the end (inside the timed
 region); value = total frames of all ranks / max-over-ranks time  ("scaling": "weak").
 
-Prints ONE JSON line on rank 0.  The CPU oracle appears here only as the timed ``cpu_baseline`` leg."""
+``value`` = frames/s with the clip already resident in HBM (the contract's definition).  The same line also carries
+``pcie_inclusive`` (SURVEY §8d's definition: the frames start in HOST memory; measured from pageable memory through the library's
+pinned ring and from pinned memory), ``exact_family`` (the fp32 kernel family, whose records are bit-identical to the oracle's: a
+short run of the same path), ``roofline`` (MFMA, the convolution family) and ``roofline_hbm`` (the bandwidth-bound kernels K1/K4/K5/K6/K7
+against 8 TB/s, from HIP events on their launch streams and their algorithmic bytes).
+
+Prints ONE JSON line on rank 0.  The CPU oracle appears here only as the timed ``cpu_baseline`` leg.  At N = 1 torch is not imported
+before the GPU work (the library has its own streams and synchronises its calls itself)."""
 import argparse
 import json
 import os
@@ -75,7 +82,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the network phase as a hipGraph (no gain once a step is GPU-bound)")
-    ap.add_argument("--host-frames", action="store_true", help="also time the PCIe-inclusive path (frames in pageable host memory, eagle_process_frames); reported as pcie_inclusive, never as value")
+    ap.add_argument("--host-frames", action="store_true", help="(kept for compatibility: the PCIe-inclusive path is always timed at N = 1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / exact_family / roofline_hbm (profiling runs)")
+    ap.add_argument("--exact-frames", type=int, default=100, help="frames of the fp32 exact-family run")
     ap.add_argument("--cadence", type=int, default=0, metavar="FPS", help="also time the reference's default cadence on the same clip: get_coordinates(frames, FPS, num_homography=1, "
                     "num_keypoint_detection=3) = HRNet every int(FPS/3)-th frame, optical-flow propagation in between (stateful; reported as reference_cadence, never as value)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
@@ -89,11 +98,11 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
-    import torch
-    dist = None
+    dist = torch = None
     dev_index = 0 if a.shared_gpu else local_rank
     tdev = "cuda" if a.backend == "nccl" else "cpu"
     if world > 1:
+        import torch
         import torch.distributed as dist
         if a.backend == "nccl":
             torch.cuda.set_device(dev_index)
@@ -136,9 +145,7 @@ def main():
     if gathered is not None:
         gathered.view(np.uint8)[::4096] = 0          # touch the pages before the timed region
 
-    def sync():
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+    def sync():                                        # every library call returns with its records on the host: nothing is in flight
         if dist is not None:
             dist.barrier()
 
@@ -161,13 +168,28 @@ def main():
     assert len(allrec) == total_frames
     log(f"timed region {dt:.3f} s -> {total_frames / dt:.1f} frames/s")
 
+    extras = world == 1 and not a.no_extras
     pcie = None
-    if a.host_frames:
+    if extras:
+        # SURVEY §8d's metric: the clip starts in host memory.  (a) pageable numpy memory -> worker threads -> pinned ring -> DMA;
+        # (b) pinned memory (eagle_host_alloc: where a decoder would write its frames) -> DMA in place.
         h.process(clip[:2 * B])
         t1 = time.perf_counter()
         h.process(clip)
-        pcie = n_local / (time.perf_counter() - t1)
-        log(f"PCIe-inclusive (pageable host frames): {pcie:.1f} frames/s")
+        r_page = n_local / (time.perf_counter() - t1)
+        hp = h.host_frames(n_local)
+        hp[:] = clip
+        h.process(hp[:2 * B])
+        t1 = time.perf_counter()
+        h.process(hp)
+        r_pin = n_local / (time.perf_counter() - t1)
+        h.host_free(hp)
+        pcie = {"value": round(r_page, 2), "unit": "frames/s", "frac_of_resident": round(r_page / (total_frames / dt), 4),
+                "pinned_source": round(r_pin, 2), "pinned_frac_of_resident": round(r_pin / (total_frames / dt), 4),
+                "note": "eagle_process_frames: value = frames in pageable host memory (copied into the library's pinned ring by "
+                        f"{os.environ.get('EAGLE_COPY_THREADS', '8')} worker threads, then DMA on a copy stream under the networks of the previous batch); "
+                        "pinned_source = frames in eagle_host_alloc memory, DMA in place"}
+        log(f"PCIe-inclusive: {r_page:.1f} frames/s from pageable memory, {r_pin:.1f} from pinned memory")
 
     cadence = None
     if a.cadence > 0:
@@ -188,23 +210,55 @@ def main():
         log(f"reference cadence @{a.cadence} fps: {cadence['value']} frames/s ({cadence['hrnet_frames']} HRNet frames)")
 
     # dominant kernel = the implicit-GEMM convolution family: per-launch HIP events on the launch stream
-    h.set_profiling(1)
-    prof_steps = 2
-    conv_ms = conv_flop = 0.0
-    n_conv = 0
-    for _ in range(prof_steps):
-        h.process_device(d_clip, B, out[:B])
-        t = h.timings()
-        conv_ms += t.conv_ms; conv_flop += t.conv_flop; n_conv += t.n_conv_launches
-    h.set_profiling(0)
+    def profile(hh, dptr, nb, prof_steps=2):
+        hh.set_profiling(1)
+        ms = flop = 0.0
+        nc = 0
+        o = np.zeros(nb, lib.RESULT_DTYPE)
+        for _ in range(prof_steps):
+            hh.process_device(dptr, nb, o)
+            t = hh.timings()
+            ms += t.conv_ms; flop += t.conv_flop; nc += t.n_conv_launches
+        kt = hh.kernel_times()
+        hh.set_profiling(0)
+        return ms, flop, nc, kt, prof_steps
+    conv_ms, conv_flop, n_conv, ktimes, prof_steps = profile(h, d_clip, B)
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # bandwidth-bound kernels: algorithmic bytes (inputs once + outputs once, counted by the library per launch) / HIP-event time
+    hbm_rows = []
+    for name, ms, launches, nbytes in ktimes:
+        if nbytes > 0 and ms > 0:
+            gbps = nbytes / (ms * 1e-3) / 1e9
+            hbm_rows.append({"kernel": name, "launches_per_step": launches // prof_steps, "bytes_algorithmic_per_step": round(nbytes / prof_steps),
+                             "avg_us": round(ms * 1e3 / launches, 2), "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)})
 
-    traffic = None
+    exact = None
+    if extras and a.precision == "f16" and a.exact_frames > 0:
+        # the exact family (fp32 tensors, v_mfma_f32_16x16x4_f32 fmaf chains): the kernels whose records equal the oracle's bit for bit
+        Be = min(B, 25)
+        ne = max(Be, a.exact_frames // Be * Be)
+        he = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz, batch=Be, precision=lib.PREC_F32)
+        weights.load_into(he, [hs, ys])
+        oe = np.zeros(ne, lib.RESULT_DTYPE)
+        he.process_device(d_clip, Be, oe[:Be])
+        t1 = time.perf_counter()
+        he.process_device(d_clip, ne, oe)
+        dte = time.perf_counter() - t1
+        ems, eflop, enc, _, _ = profile(he, d_clip, Be, 1)
+        he.close()
+        each = eflop / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
+        exact = {"dtype": "f32", "value": round(ne / dte, 2), "unit": "frames/s", "frames": ne, "frames_per_step": Be,
+                 "roofline": {"bound": "mfma", "kernel": "conv_f32_kernel", "achieved": round(each, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(each / 157.3, 4)},
+                 "note": "same path and clip with EAGLE_PREC_F32: records bit-identical to the CPU oracle (tests/test_gpu_pipeline.py::test_f32_path_identical_to_oracle)"}
+        log(f"exact family (fp32): {exact['value']} frames/s, conv {each:.1f} TFLOP/s")
+
+    traffic = traffic_src = None
     tf = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
     if os.path.exists(tf):
         tj = json.load(open(tf))
         if tj.get("batch") == B and tj.get("detector") == a.detector and tj.get("precision") == a.precision:
             traffic = tj["conv_family"]["hbm_bytes_per_launch"]
+            traffic_src = f"NOT measured in this run: read from profiles/conv_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build {tj.get('build', '?')})"
     res = None
     if rank == 0:
         res = {
@@ -220,15 +274,21 @@ def main():
                          "frac": round(achieved / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
                          "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
                          "conv_ms_per_step": round(conv_ms / prof_steps, 3),
-                         "algorithmic_bytes_note": "MFMA-bound kernel: achieved is FLOP-based; traffic = measured HBM bytes per conv launch (PMC)",
-                         "traffic": traffic},
+                         "traffic": traffic, "traffic_source": traffic_src},
+            "value_is": "frames/s with the clip resident in HBM before the timed region (records land on the host inside it); pcie_inclusive.value is the same path fed from host memory",
         }
+        if hbm_rows:
+            res["roofline_hbm"] = hbm_rows
+        if exact is not None:
+            res["exact_family"] = exact
         if cadence is not None:
             res["reference_cadence"] = cadence
         if pcie is not None:
-            res["pcie_inclusive"] = {"value": round(pcie, 2), "unit": "frames/s", "note": "frames in pageable host memory -> eagle_process_frames (H2D overlapped on a copy stream)"}
+            res["pcie_inclusive"] = pcie
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())))
+            if world == 1 and usable_cpus() > 16 and not a.no_extras:      # torch-CPU convolutions stop scaling long before 256 threads: both figures, stated
+                res["cpu_baseline_all_cores"] = cpu_baseline(hs, ys, frames, a.cpu_frames, usable_cpus(), budget_s=15.0)
     h.free(d_clip)
     h.close()
     if dist is not None:

@@ -16,6 +16,20 @@ import time
 import numpy as np
 
 
+def load_state_dict(path):
+    """A checkpoint file -> {name: float32 ndarray}.  torch is used only here, to read the file (weight loading is the one place the
+    north star allows it)."""
+    import torch
+    obj = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(obj, dict) and "model" in obj and hasattr(obj["model"], "state_dict"):      # ultralytics checkpoint
+        obj = obj["model"].float().state_dict()
+    elif hasattr(obj, "state_dict"):
+        obj = obj.state_dict()
+    elif isinstance(obj, dict) and "state_dict" in obj:
+        obj = obj["state_dict"]
+    return {k: v.detach().float().cpu().numpy() for k, v in obj.items() if hasattr(v, "detach") and v.ndim >= 0 and not k.endswith("num_batches_tracked")}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--clip", help=".npy file with uint8 [n,h,w,3] BGR frames (default: synthetic clip)")
@@ -32,6 +46,9 @@ def main(argv=None):
     ap.add_argument("--num-keypoint-detection", type=int, default=3, help="key-point model runs per second (main.py:27: 3)")
     ap.add_argument("--every-frame", action="store_true", help="key-points and homography on every frame (stateless configuration)")
     ap.add_argument("--calibration", action="store_true")
+    ap.add_argument("--keypoint-weights", help="HRNet state-dict (.pth as the reference loads at cm.py:58-59: keys unnormalized_model.0.* / unnormalized_model.1.*)")
+    ap.add_argument("--detector-weights", help="detector checkpoint: a torch state-dict (.pth) with ultralytics key names model.N.*, or an ultralytics .pt whose 'model' entry has .state_dict()")
+    ap.add_argument("--synthetic-weights", action="store_true", help="run with seeded RANDOM networks (plumbing / benchmarking only: the coordinates are meaningless)")
     ap.add_argument("--native-fps", type=float, default=None, help="frame rate of --clip: sample it down to --fps the way read_video does (io.py:17-25)")
     a = ap.parse_args(argv)
 
@@ -42,8 +59,19 @@ def main(argv=None):
         from . import io as eio
         frames, _ = eio.read_clip(frames, a.native_fps, a.fps)
     n, h, w, _ = frames.shape
+    hs = ys = None
+    if a.keypoint_weights:
+        hs = load_state_dict(a.keypoint_weights)
+    if a.detector_weights:
+        ys = load_state_dict(a.detector_weights)
+    if (hs is None or ys is None) and not a.synthetic_weights:
+        raise SystemExit("no checkpoints given: pass --keypoint-weights and --detector-weights (the reference's keypoints_main.pth / detector_*.pt, cm.py:54-59), "
+                         "or --synthetic-weights to run seeded random networks on purpose")
+    if hs is None or ys is None:
+        print("WARNING: running with seeded RANDOM network weights: the output has the reference's schema but no meaning", flush=True)
     model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
-                            precision=a.precision, device=a.device, seed=a.seed)
+                            precision=a.precision, device=a.device, seed=a.seed,
+                            hrnet_state_dict=hs, detector_state_dict=ys)
     t0 = time.perf_counter()
     nh, nk = (a.fps, a.fps) if a.every_frame else (a.num_homography, a.num_keypoint_detection)
     coordinates = model.get_coordinates(frames, a.fps, num_homography=nh, num_keypoint_detection=nk, verbose=False, calibration=a.calibration)

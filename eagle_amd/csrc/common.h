@@ -27,6 +27,10 @@ struct Err {
                                             __FILE__, __LINE__);                                       \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes are per device, and handles on
+// different devices / threads may launch the same kernel concurrently.
+void ensure_max_dynamic_lds(const void* fn, int bytes);
+
 // A view of an NHWC activation: C channels starting at channel `off` of a buffer whose pixel stride is `cs`.
 struct TView {
     void* p = nullptr;   // device base pointer of the underlying buffer

@@ -15,6 +15,7 @@
 // Epilogue: v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); store (fp16 RNE / fp32).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 #include "dmath.h"
@@ -1058,11 +1059,13 @@ void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int c
     }
 }
 
+static std::mutex g_page_mutex;
 static const void* conv_zero_page()
 {
     static void* z[64] = {};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_page_mutex);
     if (!z[dev]) { HIP_CHECK(hipMalloc(&z[dev], 256)); HIP_CHECK(hipMemset(z[dev], 0, 256)); }
     return z[dev];
 }
@@ -1071,6 +1074,7 @@ static void* conv_trash_page()
     static void* z[64] = {};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_page_mutex);
     if (!z[dev]) HIP_CHECK(hipMalloc(&z[dev], 8192));
     return z[dev];
 }
@@ -1099,12 +1103,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
     }
     const size_t lds = lds_bytes(precision, c);
-    static bool attr_done[sizeof(g_inst) / sizeof(g_inst[0])] = {};
-    const size_t ii = inst - g_inst;
-    if (!attr_done[ii]) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)inst->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done[ii] = true;
-    }
+    ensure_max_dynamic_lds((const void*)inst->fn, 160 * 1024);
     const int gy = c.cout_pad / (c.nt * 16);
     int gx = a.tiles_x * a.tiles_y * a.N;
     const bool dma = c.variant == 1 || c.variant == 5;

@@ -186,8 +186,7 @@ void nms_launch(const DetScratch& sc, int n, const PostParams& pp, EagleFrameRes
     while (cap < sc.A) cap <<= 1;
     a.cap = cap;
     const size_t lds = (size_t)cap * 9;
-    static bool done = false;
-    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); done = true; }
+    ensure_max_dynamic_lds((const void*)nms_kernel, 160 * 1024 - 2048);
     if (lds > 160 * 1024 - 2048) fail(EAGLE_E_INVALID, "too many anchors for the NMS workgroup: %d", sc.A);
     hipLaunchKernelGGL(nms_kernel, dim3(n), dim3(NMS_T), lds, s, a);
     HIP_CHECK(hipGetLastError());

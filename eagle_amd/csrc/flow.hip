@@ -523,7 +523,7 @@ void lk_launch(const ClipView& cv, int src_frame, int dst_frame, ChainState* st,
     void (*fn)(LkArgs) = lk_kernel<256, 0>;
     if (g_lk.threads == 64) fn = g_lk.dbg == 0 ? lk_kernel<64, 0> : (g_lk.dbg == 1 ? lk_kernel<64, 1> : (g_lk.dbg == 2 ? lk_kernel<64, 2> : lk_kernel<64, 4>));
     else if (g_lk.dbg) fn = g_lk.dbg == 1 ? lk_kernel<256, 1> : (g_lk.dbg == 2 ? lk_kernel<256, 2> : (g_lk.dbg == 4 ? lk_kernel<256, 4> : lk_kernel<256, 8>));
-    if (g_lk.excl_lds > 0) HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_lk.excl_lds));
+    if (g_lk.excl_lds > 0) ensure_max_dynamic_lds((const void*)fn, g_lk.excl_lds);
     hipLaunchKernelGGL(fn, dim3(EAGLE_N_LANDMARKS), dim3(g_lk.threads), (size_t)g_lk.excl_lds, s, a);
     HIP_CHECK(hipGetLastError());
 }

@@ -10,6 +10,8 @@
 // bit-for-bit.  RANSAC's sequential semantics are preserved: subsets are drawn serially from the MWC generator,
 // the 4-point models of a batch of iterations are solved in parallel (they do not depend on the running best),
 // and the batch is then replayed in iteration order with the adaptive iteration bound.
+#include <mutex>
+
 #include "common.h"
 #include "pitch_table.h"
 
@@ -1147,8 +1149,10 @@ __global__ __launch_bounds__(64) void decode_mem_kernel(DecodeArgs a)
 static const unsigned* ransac_rng_table()
 {
     static const unsigned* tab[64] = {};
+    static std::mutex m;
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(m);
     if (!tab[dev]) {
         std::vector<unsigned> h(RNG_N);
         unsigned long long st = 0xffffffffffffffffULL;
@@ -1164,8 +1168,7 @@ static const unsigned* ransac_rng_table()
 void post_launch(const ArgmaxPart* parts, int n, const PostParams& pp, EagleFrameResult* d_out, hipStream_t s)
 {
     PostArgs a; a.parts = parts; a.pp = pp; a.out = d_out; a.rng_raw = ransac_rng_table();
-    static bool done = false;
-    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PostShared))); done = true; }
+    ensure_max_dynamic_lds((const void*)post_kernel, (int)sizeof(PostShared));
     hipLaunchKernelGGL(post_kernel, dim3(n), dim3(POST_T), sizeof(PostShared), s, a);
     HIP_CHECK(hipGetLastError());
 }
@@ -1238,8 +1241,7 @@ void homography_only_launch(const float* d_img, const float* d_world, int npts, 
                             double* d_H, uint8_t* d_mask, int* d_ok, hipStream_t s)
 {
     HomoArgs a{d_img, d_world, npts, thresh, max_iters, lm_iters, d_H, d_mask, d_ok, ransac_rng_table()};
-    static bool done = false;
-    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)homography_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HomoShared))); done = true; }
+    ensure_max_dynamic_lds((const void*)homography_kernel, (int)sizeof(HomoShared));
     hipLaunchKernelGGL(homography_kernel, dim3(1), dim3(POST_T), sizeof(HomoShared), s, a);
     HIP_CHECK(hipGetLastError());
 }
@@ -1255,8 +1257,7 @@ void chain_launch(const ClipView& cv, ChainState* st, const MemList* mem, EagleF
                   int kint, int hint, int calib, hipStream_t s)
 {
     ChainArgs a{cv, st, mem, recs, pp, ransac_rng_table(), frame, kint, hint, calib};
-    static bool done = false;
-    if (!done) { HIP_CHECK(hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChainShared))); done = true; }
+    ensure_max_dynamic_lds((const void*)chain_kernel, (int)sizeof(ChainShared));
     hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(POST_T), sizeof(ChainShared), s, a);
     HIP_CHECK(hipGetLastError());
 }

@@ -5,7 +5,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstring>
 #include <functional>
@@ -29,16 +33,74 @@ void fail(int code, const char* fmt, ...)
     throw Err{code, buf};
 }
 
+void ensure_max_dynamic_lds(const void* fn, int bytes)
+{
+    static std::mutex m;
+    static std::map<std::pair<const void*, int>, int> done;      // (kernel, device) -> bytes already granted
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(m);
+    auto it = done.find({fn, dev});
+    if (it != done.end() && it->second >= bytes) return;
+    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[{fn, dev}] = bytes;
+}
+
 static thread_local std::string g_create_error;
 static int g_dbg_skip = 0;      // developer bisection (eagle_debug "skip"): 1 HRNet, 2 detector, 4 decode + NMS, 8 geometry kernel, 16 preprocess, 32 heat-map maxima, 64 fuse_sum / pool / upsample ops, 128 convolutions
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
+
+// A few host threads that copy caller frames (pageable memory) into the pinned staging ring in parallel: one memcpy thread moves
+// 5-8 GB/s, the per-frame path needs 2.76 MB x ~1800 frames/s = 5 GB/s on top of the PCIe transfer itself.
+class CopyPool {
+public:
+    explicit CopyPool(int n) { for (int i = 0; i < n; ++i) th_.emplace_back([this] { work(); }); }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // fn(k) for k in [0, n), spread over the workers; returns when all are done
+    void run(int n, const std::function<void(int)>& fn)
+    {
+        if (n <= 0) return;
+        std::unique_lock<std::mutex> g(m_);
+        fn_ = &fn; next_ = 0; n_ = n; left_ = n;
+        cv_.notify_all();
+        done_.wait(g, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void work()
+    {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return quit_ || (fn_ && next_ < n_); });
+            if (quit_) return;
+            const int k = next_++;
+            const std::function<void(int)>* f = fn_;
+            g.unlock();
+            (*f)(k);
+            g.lock();
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, n_ = 0, left_ = 0;
+    bool quit_ = false;
+};
 
 // ------------------------------------------------------------------------------------------------------------
 struct Op {
     enum Kind { CONV, OTHER, FORK, JOIN } kind = OTHER;
     std::function<void(hipStream_t)> run;
     double flop = 0;
+    double bytes = 0;        // OTHER ops: algorithmic HBM bytes of one launch (inputs read once + outputs written once)
     const char* tag = "";
     int stream = 0;          // 0: the network's own stream; 1..3: HRNet branch streams (concurrent branches between fuses)
     int nbranch = 0;         // FORK/JOIN: number of side streams involved
@@ -95,11 +157,14 @@ struct EagleHandle {
         EagleFrameResult* d_out = nullptr;
         EagleFrameResult* h_out = nullptr;   // pinned
         uint8_t* d_frames = nullptr;         // staging copy of the batch (stable pointer for the captured graph)
+        uint8_t* h_frames = nullptr;         // pinned ring slot for caller frames that live in pageable memory (allocated on first use)
+        bool copy_pending = false;           // ev_copy has been recorded for this slot
         hipEvent_t ev_compute = nullptr, ev_done = nullptr, ev_copy = nullptr;
         hipGraphExec_t gexec = nullptr;
         const uint8_t* g_src = nullptr; int g_n = 0;
     } sb[2];
     std::unique_ptr<Net> hr, yo, misc;
+    std::unique_ptr<CopyPool> pool;          // host-side copy workers (eagle_process_frames from pageable memory)
     // step buffers
     TView kp_in, det_in, logits;
     LetterBox lb;
@@ -111,6 +176,10 @@ struct EagleHandle {
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> conv_ev;
+    struct Span { int k; double bytes; hipEvent_t a, b; };
+    std::vector<hipEvent_t> span_pool; size_t span_used = 0;
+    std::vector<Span> spans;                     // non-convolution launches of the step being profiled
+    std::vector<EagleKernelTime> ktab;           // accumulated per kernel name since eagle_set_profiling(1)
     EagleTimings timings{};
     double conv_flop_step = 0; int n_conv = 0, n_launch = 0;
     // clip session of the optical-flow cadence (eagle_clip_*)
@@ -223,9 +292,10 @@ struct Builder {
         net->ops.push_back(op);
         return L.y;
     }
-    void other(std::function<void(hipStream_t)> fn, const char* tag)
+    static double vbytes(const TView& v) { return (double)v.n * v.h * v.w * v.c * (v.f32 ? 4 : 2); }
+    void other(std::function<void(hipStream_t)> fn, const char* tag, double bytes = 0)
     {
-        Op op; op.kind = Op::OTHER; op.run = std::move(fn); op.tag = tag; op.stream = cur_stream;
+        Op op; op.kind = Op::OTHER; op.run = std::move(fn); op.tag = tag; op.stream = cur_stream; op.bytes = bytes;
         net->ops.push_back(op);
     }
 };
@@ -289,7 +359,8 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
             if (nu) {
                 TView o = B.act(y.h, y.w, y.c);
                 const TView base = y; FuseUp u0 = ups[0], u1 = ups[1], u2 = ups[2]; const int n_up = nu;
-                B.other([base, u0, u1, u2, n_up, o](hipStream_t s) { FuseUp u[3] = {u0, u1, u2}; fuse_sum_launch(base, u, n_up, 1, o, s); }, "fuse");
+                B.other([base, u0, u1, u2, n_up, o](hipStream_t s) { FuseUp u[3] = {u0, u1, u2}; fuse_sum_launch(base, u, n_up, 1, o, s); }, "fuse_sum",
+                        Builder::vbytes(base) + Builder::vbytes(o) + (nu > 0 ? Builder::vbytes(ups[0].z) : 0) + (nu > 1 ? Builder::vbytes(ups[1].z) : 0) + (nu > 2 ? Builder::vbytes(ups[2].z) : 0));
                 for (int k = 0; k < nu; ++k) B.release(ups[k].z);
                 if (i != 0) B.release(y);
                 y = o;
@@ -408,21 +479,21 @@ static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3
         TView cat = B.act(h5, w5, 4 * ch);
         TView s0 = cat.slice(0, ch), s1 = cat.slice(ch, ch), s2 = cat.slice(2 * ch, ch), s3 = cat.slice(3 * ch, ch);
         Y.cv(x8, "model.9.cv1", 1, nullptr, &s0); B.release(x8);
-        B.other([s0, s1](hipStream_t s) { maxpool5_launch(s0, s1, s); }, "maxpool");
-        B.other([s1, s2](hipStream_t s) { maxpool5_launch(s1, s2, s); }, "maxpool");
-        B.other([s2, s3](hipStream_t s) { maxpool5_launch(s2, s3, s); }, "maxpool");
+        B.other([s0, s1](hipStream_t s) { maxpool5_launch(s0, s1, s); }, "maxpool5", 2 * Builder::vbytes(s0));
+        B.other([s1, s2](hipStream_t s) { maxpool5_launch(s1, s2, s); }, "maxpool5", 2 * Builder::vbytes(s0));
+        B.other([s2, s3](hipStream_t s) { maxpool5_launch(s2, s3, s); }, "maxpool5", 2 * Builder::vbytes(s0));
         Y.cv(cat, "model.9.cv2", 1, nullptr, &p5);
         B.release(cat);
     }
     {
         TView u = cat12.slice(0, c5);
-        B.other([p5, u](hipStream_t s) { upsample2_launch(p5, u, s); }, "up2");
+        B.other([p5, u](hipStream_t s) { upsample2_launch(p5, u, s); }, "upsample2", Builder::vbytes(p5) + Builder::vbytes(u));
         Y.c2f(cat12, 12, c4, d.n[0], false, &h12);
     }
     TView h15;
     {
         TView u = cat15.slice(0, c4);
-        B.other([h12, u](hipStream_t s) { upsample2_launch(h12, u, s); }, "up2");
+        B.other([h12, u](hipStream_t s) { upsample2_launch(h12, u, s); }, "upsample2", Builder::vbytes(h12) + Builder::vbytes(u));
         h15 = Y.c2f(cat15, 15, c3, d.n[0], false);
     }
     {
@@ -455,6 +526,27 @@ static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3
 // ------------------------------------------------------------------------------------------------------------
 // step execution
 // ------------------------------------------------------------------------------------------------------------
+// profiling mode only: HIP events around one non-convolution launch on stream st (the stream the kernel is launched on)
+static int ktab_index(EagleHandle* h, const char* name)
+{
+    for (size_t i = 0; i < h->ktab.size(); ++i) if (!strcmp(h->ktab[i].name, name)) return (int)i;
+    EagleKernelTime e; memset(&e, 0, sizeof(e)); strncpy(e.name, name, sizeof(e.name) - 1);
+    h->ktab.push_back(e);
+    return (int)h->ktab.size() - 1;
+}
+template <class F>
+static void timed(EagleHandle* h, const char* name, double bytes, hipStream_t st, F&& fn)
+{
+    if (!h->prof) { fn(); return; }
+    while (h->span_pool.size() < h->span_used + 2) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); h->span_pool.push_back(e); }
+    EagleHandle::Span sp{ktab_index(h, name), bytes, h->span_pool[h->span_used], h->span_pool[h->span_used + 1]};
+    h->span_used += 2;
+    HIP_CHECK(hipEventRecord(sp.a, st));
+    fn();
+    HIP_CHECK(hipEventRecord(sp.b, st));
+    h->spans.push_back(sp);
+}
+
 static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
 {
     const bool multi = h->multi_stream && !h->prof;
@@ -482,7 +574,7 @@ static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
             op.run(st);
             HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], st));
         } else {
-            op.run(st);
+            timed(h, op.tag, op.bytes, st, [&] { op.run(st); });
         }
     }
 }
@@ -495,7 +587,10 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     EagleHandle::StepBuf& sb = h->sb[p];
     size_t ev_i = 0;
     HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
-    if (!(g_dbg_skip & 16)) preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main);
+    const double esz = h->prec == EAGLE_PREC_F16 ? 2 : 4;
+    if (!(g_dbg_skip & 16))
+        timed(h, "preprocess", (double)n_active * ((double)c.frame_h * c.frame_w * 3 + (540.0 * 960 + (double)h->lb.out_h * h->lb.out_w) * h->kp_in.c * esz), h->s_main,
+              [&] { preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main); });
     const bool two = !h->prof;
     hipStream_t sd = two ? h->s_det : h->s_main;
     if (two) {
@@ -504,12 +599,14 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     }
     if (!(g_dbg_skip & 2)) run_net(h, h->yo.get(), sd, ev_i);            // detector branch
     if (!(g_dbg_skip & 4)) {
-        yolo_decode_launch(h->levels, 3, B, 5, c.detector_floor, h->ds, sd);
-        nms_launch(h->ds, B, h->pp, sb.d_out, sd);
+        // (64 box logits + 16-padded class logits) fp32 in, 4 box floats + confidence + class + sort key out, per anchor
+        timed(h, "yolo_decode", (double)B * h->ds.A * ((64 + 16) * 4.0 + 4 * 4 + 4 + 4 + 8), sd, [&] { yolo_decode_launch(h->levels, 3, B, 5, c.detector_floor, h->ds, sd); });
+        timed(h, "nms", (double)B * h->ds.A * 8.0, sd, [&] { nms_launch(h->ds, B, h->pp, sb.d_out, sd); });      // the key array, read once
     }
     if (two) HIP_CHECK(hipEventRecord(h->ev_det, sd));
     if (!(g_dbg_skip & 1)) run_net(h, h->hr.get(), h->s_main, ev_i);     // keypoint branch
-    if (!(g_dbg_skip & 32)) heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
+    if (!(g_dbg_skip & 32))
+        timed(h, "heat_argmax", (double)h->logits.n * h->logits.h * h->logits.w * h->logits.cs * 4.0, h->s_main, [&] { heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main); });
     if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));     // join
 }
 
@@ -542,7 +639,7 @@ static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_activ
         HIP_CHECK(hipEventRecord(sb.ev_compute, h->s_main));
         HIP_CHECK(hipStreamWaitEvent(sp, sb.ev_compute, 0));
     }
-    if (!(g_dbg_skip & 8)) post_launch(sb.parts, c.batch, h->pp, sb.d_out, sp);
+    if (!(g_dbg_skip & 8)) timed(h, "post (geometry)", 0, sp, [&] { post_launch(sb.parts, c.batch, h->pp, sb.d_out, sp); });
     HIP_CHECK(hipMemcpyAsync(sb.h_out, sb.d_out, sizeof(EagleFrameResult) * n_active, hipMemcpyDeviceToHost, sp));
     HIP_CHECK(hipEventRecord(sb.ev_done, sp));
 }
@@ -560,6 +657,13 @@ static void collect_step(EagleHandle* h, int p, int n_active, EagleFrameResult* 
             HIP_CHECK(hipEventElapsedTime(&t, h->conv_ev[i], h->conv_ev[i + 1]));
             h->timings.conv_ms += t;
         }
+        for (const EagleHandle::Span& sp : h->spans) {
+            float t = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&t, sp.a, sp.b));
+            EagleKernelTime& e = h->ktab[sp.k];
+            e.ms += t; e.launches += 1; e.bytes += sp.bytes;
+        }
+        h->spans.clear(); h->span_used = 0;
     }
 }
 
@@ -832,11 +936,13 @@ void eagle_destroy(EagleHandle* h)
     for (auto& sb : h->sb) {
         if (sb.gexec) (void)hipGraphExecDestroy(sb.gexec);
         if (sb.h_out) (void)hipHostFree(sb.h_out);
+        if (sb.h_frames) (void)hipHostFree(sb.h_frames);
         if (sb.ev_compute) (void)hipEventDestroy(sb.ev_compute);
         if (sb.ev_done) (void)hipEventDestroy(sb.ev_done);
         if (sb.ev_copy) (void)hipEventDestroy(sb.ev_copy);
     }
     for (auto& e : h->conv_ev) (void)hipEventDestroy(e);
+    for (auto& e : h->span_pool) (void)hipEventDestroy(e);
     h->hr.reset(); h->yo.reset(); h->misc.reset();
     if (h->s_main) (void)hipStreamDestroy(h->s_main);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
@@ -859,7 +965,11 @@ int eagle_load_weights(EagleHandle* h, const char* name, const float* data, cons
     if (h->finalized) fail(EAGLE_E_STATE, "weights already finalized");
     HostTensor t;
     size_t n = 1;
-    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    if (ndim > 0 && !shape) fail(EAGLE_E_INVALID, "bad weight tensor");
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] <= 0 || shape[i] > (1ll << 31) || n * (size_t)shape[i] > ((size_t)1 << 33)) fail(EAGLE_E_INVALID, "%s: bad dimension %lld", name, (long long)shape[i]);
+        t.shape.push_back(shape[i]); n *= (size_t)shape[i];
+    }
     t.data.assign(data, data + n);
     h->weights[name] = std::move(t);
     API_END(h)
@@ -904,18 +1014,52 @@ int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t fram
     const size_t fsz = (size_t)fh * fw * 3;
     if (row_stride == 0) row_stride = (int64_t)fw * 3;
     if (frame_stride == 0) frame_stride = row_stride * fh;
-    // H2D on its own stream: the upload of batch k+1 overlaps the networks of batch k.  (The staging buffer of parity p was
-    // last read by batch k-2, whose records the host has already collected.)
+    // H2D on its own stream: the upload of batch k+1 overlaps the networks of batch k.  (The device staging buffer of parity p
+    // was last read by batch k-2, whose records the host has already collected.)
+    //   * caller memory that is already pinned (eagle_host_alloc, hipHostMalloc, hipHostRegister): DMA straight out of it;
+    //   * pageable caller memory: worker threads copy the batch into a pinned ring slot first — an asynchronous copy out of pageable
+    //     memory is staged by the runtime on the calling thread and cost 16 % of the frame rate in round 1.
+    hipPointerAttribute_t pa;
+    bool pinned = hipPointerGetAttributes(&pa, bgr) == hipSuccess && pa.type == hipMemoryTypeHost;
+    (void)hipGetLastError();                               // an unregistered pointer is reported as an error: not one of ours
+    if (getenv("EAGLE_H2D_UNSTAGED")) pinned = true;       // developer A/B: round-1 behaviour (pageable memory handed to hipMemcpy2DAsync)
+    const bool dense = row_stride == (int64_t)fw * 3 && frame_stride == (int64_t)fsz;
+    if (!pinned && !h->pool) {
+        int nt = getenv("EAGLE_COPY_THREADS") ? atoi(getenv("EAGLE_COPY_THREADS")) : 8;
+        nt = std::max(1, std::min(nt, (int)std::max(1u, std::thread::hardware_concurrency())));
+        h->pool.reset(new CopyPool(nt));
+    }
     run_pipeline(h, n, out, [&](int p, int i, int na) -> const uint8_t* {
+        EagleHandle::StepBuf& sb = h->sb[p];
         hipStream_t sc = h->prof ? h->s_main : h->s_copy;
-        for (int k = 0; k < na; ++k)
-            HIP_CHECK(hipMemcpy2DAsync(h->sb[p].d_frames + (size_t)k * fsz, (size_t)fw * 3, bgr + (size_t)(i + k) * frame_stride,
-                                       (size_t)row_stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, sc));
-        if (!h->prof) {
-            HIP_CHECK(hipEventRecord(h->sb[p].ev_copy, sc));
-            HIP_CHECK(hipStreamWaitEvent(h->s_main, h->sb[p].ev_copy, 0));
+        const uint8_t* src = bgr + (size_t)i * frame_stride;
+        bool src_dense = dense;
+        if (!pinned) {
+            if (!sb.h_frames) HIP_CHECK(hipHostMalloc((void**)&sb.h_frames, (size_t)h->cfg.batch * fsz, hipHostMallocDefault));
+            if (sb.copy_pending) HIP_CHECK(hipEventSynchronize(sb.ev_copy));      // the DMA of batch k-2 has left this slot
+            const int parts = 4;                                                  // tasks per frame: keeps every worker busy on small batches
+            h->pool->run(na * parts, [&](int t) {
+                const int k = t / parts, q = t % parts, r0 = fh * q / parts, r1 = fh * (q + 1) / parts;
+                const uint8_t* s0 = src + (size_t)k * frame_stride;
+                uint8_t* d0 = sb.h_frames + (size_t)k * fsz;
+                if (row_stride == (int64_t)fw * 3) memcpy(d0 + (size_t)r0 * fw * 3, s0 + (size_t)r0 * row_stride, (size_t)(r1 - r0) * fw * 3);
+                else for (int r = r0; r < r1; ++r) memcpy(d0 + (size_t)r * fw * 3, s0 + (size_t)r * row_stride, (size_t)fw * 3);
+            });
+            src = sb.h_frames; src_dense = true;
         }
-        return h->sb[p].d_frames;
+        if (src_dense) {
+            HIP_CHECK(hipMemcpyAsync(sb.d_frames, src, (size_t)na * fsz, hipMemcpyHostToDevice, sc));
+        } else {
+            for (int k = 0; k < na; ++k)
+                HIP_CHECK(hipMemcpy2DAsync(sb.d_frames + (size_t)k * fsz, (size_t)fw * 3, src + (size_t)k * frame_stride,
+                                           (size_t)row_stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, sc));
+        }
+        if (!h->prof) {
+            HIP_CHECK(hipEventRecord(sb.ev_copy, sc));
+            sb.copy_pending = true;
+            HIP_CHECK(hipStreamWaitEvent(h->s_main, sb.ev_copy, 0));
+        }
+        return sb.d_frames;
     });
     API_END(h)
 }
@@ -927,17 +1071,16 @@ int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double*
     if (!recs || !Hs || !flags || n < 0) fail(EAGLE_E_INVALID, "bad argument");
     if (n == 0) return EAGLE_OK;
     HIP_CHECK(hipSetDevice(h->cfg.device));
-    EagleFrameResult* d_r = nullptr; double* d_H = nullptr; unsigned char* d_f = nullptr;
-    HIP_CHECK(hipMalloc((void**)&d_r, sizeof(EagleFrameResult) * (size_t)n));
-    HIP_CHECK(hipMalloc((void**)&d_H, sizeof(double) * 9 * (size_t)n));
-    HIP_CHECK(hipMalloc((void**)&d_f, (size_t)n));
+    Net scratch;                                          // owns the three device buffers: freed on every exit path
+    EagleFrameResult* d_r = (EagleFrameResult*)scratch.get(sizeof(EagleFrameResult) * (size_t)n);
+    double* d_H = (double*)scratch.get(sizeof(double) * 9 * (size_t)n);
+    unsigned char* d_f = (unsigned char*)scratch.get((size_t)n);
     HIP_CHECK(hipMemcpyAsync(d_r, recs, sizeof(EagleFrameResult) * (size_t)n, hipMemcpyHostToDevice, h->s_main));
     HIP_CHECK(hipMemcpyAsync(d_H, Hs, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, h->s_main));
     HIP_CHECK(hipMemcpyAsync(d_f, flags, (size_t)n, hipMemcpyHostToDevice, h->s_main));
     reproject_launch(d_r, d_H, d_f, n, h->cfg.frame_h, h->cfg.frame_w, h->s_main);
     HIP_CHECK(hipMemcpyAsync(recs, d_r, sizeof(EagleFrameResult) * (size_t)n, hipMemcpyDeviceToHost, h->s_main));
     HIP_CHECK(hipStreamSynchronize(h->s_main));
-    (void)hipFree(d_r); (void)hipFree(d_H); (void)hipFree(d_f);
     API_END(h)
 }
 
@@ -1101,10 +1244,35 @@ int eagle_device_upload(EagleHandle* h, void* dptr, const void* src, int64_t byt
     API_END(h)
 }
 
+int eagle_host_alloc(EagleHandle* h, int64_t bytes, void** ptr)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!ptr || bytes < 0) fail(EAGLE_E_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    HIP_CHECK(hipHostMalloc(ptr, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault));
+    API_END(h)
+}
+int eagle_host_free(EagleHandle* h, void* ptr)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    HIP_CHECK(hipHostFree(ptr));
+    API_END(h)
+}
+
 int eagle_set_profiling(EagleHandle* h, int on)
 {
     if (!h) return EAGLE_E_INVALID;
     h->prof = on != 0;
+    if (h->prof) h->ktab.clear();
+    return EAGLE_OK;
+}
+int eagle_get_kernel_times(EagleHandle* h, EagleKernelTime* out, int cap, int* n)
+{
+    if (!h || !n || (cap > 0 && !out)) return EAGLE_E_INVALID;
+    *n = (int)h->ktab.size();
+    for (int i = 0; i < *n && i < cap; ++i) out[i] = h->ktab[i];
     return EAGLE_OK;
 }
 int eagle_get_timings(EagleHandle* h, EagleTimings* t)

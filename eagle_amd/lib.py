@@ -33,6 +33,10 @@ class EagleTimings(C.Structure):
                 ("n_conv_launches", C.c_int32), ("conv_flop", C.c_double), ("reserved", C.c_int32 * 8)]
 
 
+class EagleKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("ms", C.c_float), ("launches", C.c_int32), ("bytes", C.c_double)]
+
+
 # numpy mirrors of the record structs (C layout, natural alignment — checked against sizeof in tests)
 DET_DTYPE = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("conf", "<f4"), ("cls", "<i4"),
                       ("id", "<i4"), ("bx1", "<i4"), ("by1", "<i4"), ("bx2", "<i4"), ("by2", "<i4"),
@@ -71,6 +75,8 @@ def load():
     L.eagle_finalize_weights.argtypes = [vp]
     L.eagle_process_frames.argtypes = [vp, u8p, i32, i64, i64, vp]
     L.eagle_process_device_frames.argtypes = [vp, vp, i32, vp]
+    L.eagle_host_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+    L.eagle_host_free.argtypes = [vp, vp]
     L.eagle_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
     L.eagle_device_free.argtypes = [vp, vp]
     L.eagle_device_upload.argtypes = [vp, vp, vp, i64]
@@ -89,6 +95,7 @@ def load():
     L.eagle_gather.argtypes = [vp, vp, i32, vp]
     L.eagle_set_profiling.argtypes = [vp, i32]
     L.eagle_get_timings.argtypes = [vp, C.POINTER(EagleTimings)]
+    L.eagle_get_kernel_times.argtypes = [vp, C.POINTER(EagleKernelTime), i32, C.POINTER(i32)]
     L.eagle_op_conv2d.argtypes = [i32, i32, fp, i32, i32, i32, i32, fp, fp, i32, i32, i32, i32, fp, fp, i32, fp]
     L.eagle_op_fuse_sum.argtypes = [i32, i32, fp, i32, i32, i32, i32, i32, C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, fp]
     L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
@@ -100,8 +107,8 @@ def load():
 
 EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_destroy", "eagle_last_error", "eagle_load_weights",
            "eagle_finalize_weights", "eagle_process_frames", "eagle_process_device_frames", "eagle_device_alloc",
-           "eagle_device_free", "eagle_device_upload", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
-           "eagle_set_profiling", "eagle_get_timings", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
+           "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
+           "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
            "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug"]
 
@@ -186,6 +193,23 @@ class Handle:
                                                 out.ctypes.data_as(C.c_void_p)), "process_frames")
         return out
 
+    def host_frames(self, n):
+        """uint8 [n,h,w,3] array in pinned host memory (eagle_host_alloc): what a decoder should write frames into so that
+        eagle_process_frames can DMA them in place.  Release with host_free(array)."""
+        shape = (n, self.cfg.frame_h, self.cfg.frame_w, 3)
+        nbytes = int(np.prod(shape))
+        p = C.c_void_p()
+        self._check(self.L.eagle_host_alloc(self._h, nbytes, C.byref(p)), "host_alloc")
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        a = np.frombuffer(buf, np.uint8, nbytes).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a):
+        p = self._pinned.pop(a.ctypes.data)
+        self._check(self.L.eagle_host_free(self._h, p), "host_free")
+
     def upload(self, frames):
         frames = np.ascontiguousarray(frames, np.uint8)
         d = C.c_void_p()
@@ -265,6 +289,12 @@ class Handle:
         t = EagleTimings()
         self._check(self.L.eagle_get_timings(self._h, C.byref(t)), "get_timings")
         return t
+
+    def kernel_times(self):
+        """[(name, total ms, launches, algorithmic bytes)] of the non-convolution launches since set_profiling(1)."""
+        buf = (EagleKernelTime * 32)(); n = C.c_int(0)
+        self._check(self.L.eagle_get_kernel_times(self._h, buf, 32, C.byref(n)), "get_kernel_times")
+        return [(buf[i].name.decode(), float(buf[i].ms), int(buf[i].launches), float(buf[i].bytes)) for i in range(min(n.value, 32))]
 
     # --- multi-GPU -------------------------------------------------------------------------------------
     def comm_init(self, rank, world, uid_bytes):

@@ -119,9 +119,14 @@ const char* eagle_last_error(EagleHandle* h);   /* h may be NULL: last error of 
 int eagle_load_weights(EagleHandle* h, const char* name, const float* data, const int64_t* shape, int ndim);
 int eagle_finalize_weights(EagleHandle* h);
 
-/* The hot path: n BGR uint8 HWC frames (host memory, row stride in bytes) -> n records. */
+/* The hot path: n BGR uint8 HWC frames (host memory, row stride in bytes) -> n records.  This is the call that replaces the reference's
+ * per-frame loop over host frames (cm.py:277; frames come from eagle/utils/io.py::read_video).  The upload of batch k+1 overlaps the
+ * networks of batch k.  Frames in pinned memory (eagle_host_alloc: what a decoder should write into) are DMA'd in place; frames in
+ * pageable memory are first copied into a pinned ring by a few worker threads of the handle (EAGLE_COPY_THREADS, default 8). */
 int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t frame_stride, int64_t row_stride,
                          EagleFrameResult* out);
+int eagle_host_alloc(EagleHandle* h, int64_t bytes, void** ptr);   /* pinned host memory for frames */
+int eagle_host_free(EagleHandle* h, void* ptr);
 
 /* Same, inputs already resident in HBM (device pointer, dense [n,h,w,3]); records still land on the host.
  * This is the entry bench.py times ("inputs resident in HBM when the timed region starts"). */
@@ -183,6 +188,11 @@ typedef struct EagleTimings {
 } EagleTimings;
 int eagle_set_profiling(EagleHandle* h, int per_kernel_events);
 int eagle_get_timings(EagleHandle* h, EagleTimings* t);
+/* Profiling mode also times every non-convolution launch (HIP events on its launch stream) and accumulates, per kernel name, the
+ * elapsed time and the ALGORITHMIC HBM bytes of the launches (inputs read once + outputs written once): the HBM-roofline
+ * rows of bench.py.  The table is cleared by eagle_set_profiling(h, 1). */
+typedef struct EagleKernelTime { char name[32]; float ms; int32_t launches; double bytes; } EagleKernelTime;
+int eagle_get_kernel_times(EagleHandle* h, EagleKernelTime* out, int cap, int* n);
 
 /* Operator-level entry points (host buffers in/out) used by the parity tests: each runs ONE kernel of the path.
  * Tensors are dense NHWC fp32 on the host; `precision` selects the fp16 or fp32 kernel family. */

@@ -206,8 +206,9 @@ def _hr_stage(be, prm, xs, stage_idx, n_modules, nb, last_single):
     return xs
 
 
-def hrnet_logits(sd, x_nhwc, backend="c", f16=False, prm=None):
-    """x [N,540,960,3] normalised RGB -> logits [N,135,240,57] float32 (before the sigmoid)."""
+def hrnet_logits(sd, x_nhwc, backend="c", f16=False, prm=None, features=False):
+    """x [N,540,960,3] normalised RGB -> logits [N,135,240,57] float32 (before the sigmoid).
+    features=True: also the 48-channel map the head reads ([N,135,240,48]; used by tests/golden/make_peaked_head.py)."""
     be = CBackend(f16) if backend == "c" else TorchBackend()
     prm = prm or Params(sd, 1e-5, f16 and backend == "c")
     R = P.ACT_RELU
@@ -228,6 +229,8 @@ def hrnet_logits(sd, x_nhwc, backend="c", f16=False, prm=None):
     ys.append(be.conv(ys[-1], prm.get(HR + "transition3.3.0.0", HR + "transition3.3.0.1"), stride=2, post=R))
     ys = _hr_stage(be, prm, ys, 4, 3, 4, True)
     logits = be.conv(ys[0], prm.get("unnormalized_model.1", None), f32_out=True)
+    if features:
+        return be.to_nhwc(logits), np.asarray(be.to_nhwc(ys[0]), np.float32)
     return be.to_nhwc(logits)
 
 

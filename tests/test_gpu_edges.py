@@ -1,5 +1,7 @@
 """-m gpu: edge cases of the per-frame path (the reference has no tests; these are the cases its loop body guards with
 try/except or explicit checks: no detections, < 4 plane points -> no homography, empty input, ragged batches)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -108,7 +110,7 @@ def test_cli_writes_reference_schema(tmp_path):
     """configs[0]: 10-frame clip at --fps 5 -> raw_coordinates.json with the schema of docs/data.md:20-41."""
     import json
     from eagle_amd import cli
-    assert cli.main(["--frames", "10", "--fps", "5", "--out", str(tmp_path), "--batch", "4"]) == 0
+    assert cli.main(["--frames", "10", "--fps", "5", "--out", str(tmp_path), "--batch", "4", "--synthetic-weights"]) == 0
     d = json.load(open(tmp_path / "raw_coordinates.json"))
     assert sorted(d, key=int) == [str(i) for i in range(10)]
     for i, rec in d.items():
@@ -163,11 +165,11 @@ def test_cli_at_25_fps_uses_the_flow_cadence(tmp_path):
     carry the reference's value types (flowed key-points are numpy integers there, which json.dump(default=float) writes as floats)."""
     import json
     from eagle_amd import cli
-    assert cli.main(["--frames", "11", "--fps", "25", "--out", str(tmp_path), "--batch", "4"]) == 0
+    assert cli.main(["--frames", "11", "--fps", "25", "--out", str(tmp_path), "--batch", "4", "--synthetic-weights"]) == 0
     d = json.load(open(tmp_path / "raw_coordinates.json"))
     assert sorted(d, key=int) == [str(i) for i in range(11)]
     assert all(set(r) == {"Coordinates", "Time", "Keypoints", "Boundaries"} for r in d.values())
-    every = cli.main(["--frames", "11", "--fps", "25", "--out", str(tmp_path / "e"), "--batch", "4", "--every-frame"])
+    every = cli.main(["--frames", "11", "--fps", "25", "--out", str(tmp_path / "e"), "--batch", "4", "--every-frame", "--synthetic-weights"])
     assert every == 0 and len(json.load(open(tmp_path / "e" / "raw_coordinates.json"))) == 11
 
 
@@ -185,3 +187,17 @@ def test_cfg3_fp16_family_builds_and_runs():
         assert all(np.isfinite(r["hm_score"]).all() for r in recs)
     finally:
         m.handle.close()
+
+
+def test_two_ranks_on_one_gpu_equal_a_single_rank_run():
+    """The N > 1 path end to end with REAL records before any multi-GPU node exists: two fresh processes, each with its own handle
+    on device 0, frame-sharded (stateless path) and clip-sharded (flow cadence); gathered records == single-rank records."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "shard_check.py")], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0 and "SHARD_CHECK_OK world=2" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

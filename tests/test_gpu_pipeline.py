@@ -171,3 +171,142 @@ def test_f16_path_vs_f16_emulating_oracle(state_dicts, frames):
     conf = dets[dets[:, 4] >= 0.25]
     hit = [bool(((iou(d[:4], g) > 0.9) & (gcls == int(d[5]))).any()) for d in conf]
     assert len(conf) > 10 and np.mean(hit) > 0.95, f"{np.mean(hit):.2f} of {len(conf)} confident oracle detections found by the fp16 path"
+
+
+# ---- record-level parity of the fp16 (benchmarked) family ------------------------------------------------------------------------------
+def _peaked_state_dict(hs):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "peaked_head.npz"))
+    hs2 = dict(hs)
+    hs2["unnormalized_model.1.weight"] = g["weight"]; hs2["unnormalized_model.1.bias"] = g["bias"]
+    return hs2, g
+
+
+def _iou(a, b):
+    x1 = np.maximum(a[0], b[:, 0]); y1 = np.maximum(a[1], b[:, 1]); x2 = np.minimum(a[2], b[:, 2]); y2 = np.minimum(a[3], b[:, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter + 1e-9)
+
+
+def _f16_record_parity(rec, oref, aux, tag, frame_hw):
+    """One frame: the fp16 family's record against the fp16-STORAGE-emulating oracle (same rounding points, exact-order fp32 sums).
+    Returns counters for the summary line."""
+    from eagle_amd.pitch import INTERSECTION_TO_PITCH_POINTS
+    from oracle import prims as P
+    sig = P.sigmoid(aux["logits"][0]).reshape(-1, 57)
+    srt = np.sort(sig, 0)
+    margin = srt[-1] - srt[-2]
+    peaked = np.nonzero(margin > 0.05)[0]
+    flat = np.nonzero(margin == 0)[0]                   # constant maps (landmark not in view): first index on both sides
+    # (1) heat-map maxima: identical wherever the oracle's own top-1 / top-2 margin exceeds 0.05
+    bad = [int(c) for c in list(peaked) + list(flat) if int(rec["hm_idx"][c]) != int(aux["hm_idx"][c])]
+    assert not bad, f"{tag}: heat-map maxima differ on channels with a clear maximum: {bad}"
+    assert np.abs(rec["hm_score"][peaked] - aux["hm_score"][peaked]).max(initial=0) < 5e-3
+    # (2) key-point pixels (cm.py:500-518) identical
+    kp = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"])) for k in rec["kp"][: int(rec["n_kp"])] if not k["synthesized"]}
+    same_kp = kp == {k: (int(v[0]), int(v[1])) for k, v in aux["kp_detected"].items()}
+    # (3) with identical key-points the geometry must be IDENTICAL (the geometry kernel does not depend on the family): synthesis, H, inliers
+    h_checked = False
+    if same_kp:
+        allkp = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"])) for k in rec["kp"][: int(rec["n_kp"])]}
+        assert allkp == {k: (int(v[0]), int(v[1])) for k, v in aux["kp_synth"].items()}, f"{tag}: synthesised key-points differ"
+        assert bool(rec["H_valid"]) == (aux["H"] is not None), f"{tag}: H validity differs"
+        if aux["H"] is not None:
+            Hg, Ho = rec["H"].reshape(3, 3), aux["H"]
+            assert np.abs(Hg - Ho).max() <= 1e-3 * np.abs(Ho).max() and np.allclose(Hg, Ho, rtol=1e-3, atol=1e-9), f"{tag}: H differs beyond 1e-3"
+            h_checked = True
+    # (4) detections: every oracle detection has a GPU detection of the same class at IoU > 0.9 (95 %); integer boxes within 1 px
+    n = int(rec["n_det"]); dets = aux["dets"]
+    assert abs(n - len(dets)) <= max(3, 0.05 * len(dets)), f"{tag}: {n} detections vs {len(dets)}"
+    g = np.stack([rec["det"][k][:n] for k in ("x1", "y1", "x2", "y2")], 1) if n else np.zeros((0, 4), np.float32)
+    gcls = rec["det"]["cls"][:n]
+    fh, fw = frame_hw
+    match, nonident, checked_pitch = [], 0, 0
+    for i, d in enumerate(dets):
+        if n == 0:
+            match.append(-1); continue
+        io = _iou(d[:4], g) * (gcls == int(d[5]))
+        j = int(io.argmax())
+        match.append(j if io[j] > 0.9 else -1)
+    found = [m for m in match if m >= 0]
+    assert len(dets) == 0 or len(found) >= 0.95 * len(dets), f"{tag}: only {len(found)} of {len(dets)} oracle detections found"
+    for i, j in enumerate(match):
+        if j < 0:
+            continue
+        d = dets[i]
+        bi = np.array([int(d[0]), int(d[1]), int(d[2]), int(d[3])])              # astype(int) truncation (cm.py:600), before clipping
+        is_person = int(d[5]) in (0, 1)
+        if is_person:
+            bi = np.array([min(max(bi[0], 0), fw - 1), min(max(bi[1], 0), fh - 1), min(max(bi[2], 0), fw - 1), min(max(bi[3], 0), fh - 1)])
+        gi = np.array([int(rec["det"][k][j]) for k in ("bx1", "by1", "bx2", "by2")])
+        assert np.abs(gi - bi).max() <= 1, f"{tag}: integer box of detection {i} off by more than a pixel: {gi} vs {bi}"
+        nonident += int((gi != bi).any())
+    # ID order: detections whose confidences differ by more than 1e-3 keep their relative order
+    for i in range(len(dets) - 1):
+        if match[i] >= 0 and match[i + 1] >= 0 and dets[i][4] - dets[i + 1][4] > 1e-3:
+            assert match[i] < match[i + 1], f"{tag}: detection order differs where confidences are {dets[i][4]} / {dets[i + 1][4]}"
+    # (5) pitch coordinates of the reported objects: identical ints and floats within 1e-3 wherever foot point and H are identical
+    if h_checked and np.array_equal(rec["H"].reshape(3, 3), aux["H"]):
+        oobj = oref["Coordinates"]
+        for cname in ("Player", "Goalkeeper"):
+            for oid, o in oobj.get(cname, {}).items():
+                j = match[int(oid)] if int(oid) < len(match) else -1
+                if j < 0:
+                    continue
+                gd = rec["det"][j]
+                ofoot = o.get("Image_Bottom_center") or [int((o["BBox"][0] + o["BBox"][2]) / 2), o["BBox"][3]]
+                if [int(gd["foot_x"]), int(gd["foot_y"])] != [int(ofoot[0]), int(ofoot[1])]:
+                    continue
+                tc = o["Transformed_Coordinates"]
+                assert bool(gd["in_bounds"]) == (tc is not None), f"{tag}: in-bounds flag differs for object {oid}"
+                if tc is not None:
+                    assert [int(gd["pitch_x"]), int(gd["pitch_y"])] == [int(tc[0]), int(tc[1])], f"{tag}: pitch integers differ for object {oid}"
+                checked_pitch += 1
+    return dict(peaked=len(peaked), same_kp=same_kp, h_checked=h_checked, dets=len(dets), found=len(found), nonident=nonident, pitch=checked_pitch)
+
+
+def test_f16_family_record_parity_cfg2(state_dicts):
+    """The benchmarked family on cfg 2 (1280x720, yolov8n@640 + HRNet-W48) with the peaked-heat-map head of
+    tests/golden/make_peaked_head.py: heat-map maxima identical on every channel with a clear maximum (all 57 on the design frame),
+    key-point pixels, synthesised points, H and pitch coordinates identical to the fp16-emulating oracle, integer boxes within a pixel."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    from oracle import pipeline
+    hs, ys = state_dicts
+    hs2, g = _peaked_state_dict(hs)
+    frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 4), synth.frame(0, 9)])
+    cm = CoordinateModel(precision="f16", batch=2, hrnet_state_dict=hs2, detector_state_dict=ys)
+    recs = cm.process_records(frames)
+    cm.handle.close()
+    ora = pipeline.OracleModel(hs2, ys, backend="c", f16=True)
+    tot = []
+    for i, f in enumerate(frames):
+        oref, aux = ora.step(f, i)
+        tot.append(_f16_record_parity(recs[i], oref, aux, f"cfg2 frame {i}", (720, 1280)))
+    print("fp16 record parity cfg2:", tot)
+    assert tot[0]["peaked"] >= 20 and tot[0]["same_kp"] and tot[0]["h_checked"], tot[0]       # the design frame: every placed landmark, H solved and identical
+    assert sum(t["nonident"] for t in tot) <= 0.25 * max(1, sum(t["found"] for t in tot)), tot
+    # the fp32 (exact) family on the same peaked weights equals the fp32 oracle bit for bit, like on the random head
+    cm32 = CoordinateModel(precision="f32", batch=1, hrnet_state_dict=hs2, detector_state_dict=ys)
+    r32 = cm32.process_records(frames[:1])[0]
+    cm32.handle.close()
+    _, aux32 = pipeline.OracleModel(hs2, ys, backend="c").step(frames[0], 0)
+    assert np.array_equal(r32["hm_idx"], aux32["hm_idx"]) and np.array_equal(r32["hm_score"], aux32["hm_score"])
+    assert r32["H_valid"] and np.array_equal(r32["H"].reshape(3, 3), aux32["H"])
+
+
+def test_f16_family_record_parity_cfg3():
+    """The same on cfg 3 (1920x1080, yolov8l@960)."""
+    from eagle_amd import synth, weights
+    from eagle_amd.coordinate_model import CoordinateModel
+    from oracle import pipeline
+    hs, yl = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("l", 0)
+    hs2, g = _peaked_state_dict(hs)
+    frame = synth.frame(int(g["design"][0]), int(g["design"][1]), 1080, 1920)
+    cm = CoordinateModel(precision="f16", batch=1, frame_hw=(1080, 1920), detector="l", det_imgsz=960, hrnet_state_dict=hs2, detector_state_dict=yl)
+    rec = cm.process_records(frame[None])[0]
+    cm.handle.close()
+    oref, aux = pipeline.OracleModel(hs2, yl, variant="l", imgsz=960, backend="c", f16=True).step(frame, 0)
+    t = _f16_record_parity(rec, oref, aux, "cfg3", (1080, 1920))
+    print("fp16 record parity cfg3:", t)
+    assert t["nonident"] <= 0.25 * max(1, t["found"]), t

@@ -287,8 +287,8 @@ def main():
             res["pcie_inclusive"] = pcie
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())))
-            if world == 1 and usable_cpus() > 16 and not a.no_extras:      # torch-CPU convolutions stop scaling long before 256 threads: both figures, stated
-                res["cpu_baseline_all_cores"] = cpu_baseline(hs, ys, frames, a.cpu_frames, usable_cpus(), budget_s=15.0)
+            # (all 256 hardware threads of the GPU box were tried once: torch-CPU convolutions collapse to 0.004 frames/s, 247 s for one
+            #  frame, profiles/r02b_bench_default_1gpu.json, so the bounded sample stays at 16 threads and says so)
     h.free(d_clip)
     h.close()
     if dist is not None:

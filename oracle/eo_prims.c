@@ -641,6 +641,194 @@ done:
     return ok;
 }
 
+/* ---------------------------------------------------------------------------------------------------- */
+/* Second CPU mode: the solver OpenCV 4.11 itself uses (parity unpinned: cv2 is absent; restated from the published
+ * sources), to BOUND what the production mode's two deliberate deviations can change (tests/test_oracle_host.py):
+ *   (i)  runKernel for the minimal 4-point hypotheses too: 9x9 LtL + eigenvector of the smallest eigenvalue
+ *        (production: normalised 8x8 Gaussian elimination, eo_h4_homography);
+ *   (ii) cv::eigen's Jacobi (JacobiImpl_): every rotation annihilates the LARGEST off-diagonal element, found through
+ *        per-row / per-column maximum indices, at most 30 n^2 rotations, eigenvalues sorted descending
+ *        (production: cyclic sweeps, eo_jacobi9_smallest).
+ * Also cv2.LMEDS (LMeDSPointSetRegistrator), the last fall-back of cm.py:354-357. */
+/* ---------------------------------------------------------------------------------------------------- */
+static void eo_jacobi_cv(double* A, int n, double* W, double* V)
+{
+    const double eps = 2.220446049250313e-16;
+    int indR[16], indC[16];
+    int i, j, k, m;
+    double mv = 0;
+    for (i = 0; i < n; ++i) { for (j = 0; j < n; ++j) V[i * n + j] = 0; V[i * n + i] = 1; }
+    for (k = 0; k < n; ++k) {
+        W[k] = A[(n + 1) * k];
+        if (k < n - 1) { for (m = k + 1, mv = fabs(A[n * k + m]), i = k + 2; i < n; ++i) { const double val = fabs(A[n * k + i]); if (mv < val) mv = val, m = i; } indR[k] = m; }
+        if (k > 0) { for (m = 0, mv = fabs(A[k]), i = 1; i < k; ++i) { const double val = fabs(A[n * i + k]); if (mv < val) mv = val, m = i; } indC[k] = m; }
+    }
+    if (n > 1) for (int iters = 0; iters < n * n * 30; ++iters) {
+        for (k = 0, mv = fabs(A[indR[0]]), i = 1; i < n - 1; ++i) { const double val = fabs(A[n * i + indR[i]]); if (mv < val) mv = val, k = i; }
+        int l = indR[k];
+        for (i = 1; i < n; ++i) { const double val = fabs(A[n * indC[i] + i]); if (mv < val) mv = val, k = indC[i], l = i; }
+        const double p = A[n * k + l];
+        if (fabs(p) <= eps) break;
+        const double y = (W[l] - W[k]) * 0.5;
+        double t = fabs(y) + hypot(p, y);
+        double s = hypot(p, t);
+        const double c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0) s = -s, t = -t;
+        A[n * k + l] = 0;
+        W[k] -= t; W[l] += t;
+        double a0, b0;
+#define EO_CVROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
+        for (i = 0; i < k; ++i) EO_CVROT(A[n * i + k], A[n * i + l]);
+        for (i = k + 1; i < l; ++i) EO_CVROT(A[n * k + i], A[n * i + l]);
+        for (i = l + 1; i < n; ++i) EO_CVROT(A[n * k + i], A[n * l + i]);
+        for (i = 0; i < n; ++i) EO_CVROT(V[n * k + i], V[n * l + i]);
+#undef EO_CVROT
+        for (j = 0; j < 2; ++j) {
+            const int idx = j == 0 ? k : l;
+            if (idx < n - 1) { for (m = idx + 1, mv = fabs(A[n * idx + m]), i = idx + 2; i < n; ++i) { const double val = fabs(A[n * idx + i]); if (mv < val) mv = val, m = i; } indR[idx] = m; }
+            if (idx > 0) { for (m = 0, mv = fabs(A[idx]), i = 1; i < idx; ++i) { const double val = fabs(A[n * i + idx]); if (mv < val) mv = val, m = i; } indC[idx] = m; }
+        }
+    }
+    for (k = 0; k < n - 1; ++k) {                          /* descending eigenvalues; eigenvectors are the ROWS of V */
+        m = k;
+        for (i = k + 1; i < n; ++i) if (W[m] < W[i]) m = i;
+        if (k != m) { double tw = W[m]; W[m] = W[k]; W[k] = tw; for (i = 0; i < n; ++i) { double tv = V[n * m + i]; V[n * m + i] = V[n * k + i]; V[n * k + i] = tv; } }
+    }
+}
+
+/* runKernel exactly as HomographyEstimatorCallback does it, for any n >= 4 (sel: optional index list) */
+int eo_dlt_homography_cv(const double* src, const double* dst, const int* sel, int n, double* H)
+{
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = 0; i < n; ++i) { const int k = sel ? sel[i] : i; cm[0] += dst[2 * k]; cm[1] += dst[2 * k + 1]; cM[0] += src[2 * k]; cM[1] += src[2 * k + 1]; }
+    cm[0] /= n; cm[1] /= n; cM[0] /= n; cM[1] /= n;
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        sm[0] += fabs(dst[2 * k] - cm[0]); sm[1] += fabs(dst[2 * k + 1] - cm[1]);
+        sM[0] += fabs(src[2 * k] - cM[0]); sM[1] += fabs(src[2 * k + 1] - cM[1]);
+    }
+    if (fabs(sm[0]) < 2.220446049250313e-16 || fabs(sm[1]) < 2.220446049250313e-16 || fabs(sM[0]) < 2.220446049250313e-16 || fabs(sM[1]) < 2.220446049250313e-16) return 0;
+    sm[0] = n / sm[0]; sm[1] = n / sm[1]; sM[0] = n / sM[0]; sM[1] = n / sM[1];
+    double LtL[81], W[9], V[81];
+    memset(LtL, 0, sizeof(LtL));
+    for (int i = 0; i < n; ++i) {
+        const int k = sel ? sel[i] : i;
+        const double x = (dst[2 * k] - cm[0]) * sm[0], y = (dst[2 * k + 1] - cm[1]) * sm[1];
+        const double X = (src[2 * k] - cM[0]) * sM[0], Y = (src[2 * k + 1] - cM[1]) * sM[1];
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int a = 0; a < 9; ++a) for (int b = a; b < 9; ++b) LtL[a * 9 + b] += Lx[a] * Lx[b] + Ly[a] * Ly[b];
+    }
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < a; ++b) LtL[a * 9 + b] = LtL[b * 9 + a];
+    eo_jacobi_cv(LtL, 9, W, V);
+    const double* h = V + 8 * 9;                           /* row of the smallest eigenvalue */
+    const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double t[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += iT[3 * r + k] * h[3 * k + c]; t[3 * r + c] = s; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += t[3 * r + k] * T[3 * k + c]; H[3 * r + c] = s; }
+    if (fabs(H[8]) < 2.220446049250313e-16) return 0;
+    const double inv = 1.0 / H[8];
+    for (int k = 0; k < 9; ++k) H[k] *= inv;
+    H[8] = 1.0;
+    return 1;
+}
+
+static int eo_get_subset4(const double* src, const double* dst, int n, uint64_t* rng, int* idx)
+{
+    for (int attempt = 0; attempt < 1000; ++attempt) {
+        for (int i = 0; i < 4; ++i) {
+            int v, dup;
+            do { v = (int)(eo_rng_next(rng) % (uint32_t)n); dup = 0; for (int j = 0; j < i; ++j) dup |= (idx[j] == v); } while (dup);
+            idx[i] = v;
+        }
+        if (eo_check_subset4(src, dst, idx)) return 1;
+    }
+    return 0;
+}
+static int eo_cmp_float(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return (x > y) - (x < y); }
+
+/* mode 0: production deviations (8x8 minimal solver, cyclic Jacobi); mode 1: cv2's own solver throughout.
+ * method 8 = cv2.RANSAC (thresh used), 4 = cv2.LMEDS (thresh ignored; confidence 0.995, maxIters 2000 as findHomography passes them). */
+int eo_find_homography_ex(const float* srcf, const float* dstf, int n, int method, double thresh, int max_iters,
+                          double confidence, int refine_iters, int mode, double* H, uint8_t* mask)
+{
+    if (n < 4) return 0;
+    if (method == 8 && mode == 0) return eo_find_homography_ransac(srcf, dstf, n, thresh, max_iters, confidence, refine_iters, H, mask);
+    double* src = (double*)malloc(sizeof(double) * 2 * n);
+    double* dst = (double*)malloc(sizeof(double) * 2 * n);
+    float* err = (float*)malloc(sizeof(float) * n);
+    float* srt = (float*)malloc(sizeof(float) * n);
+    uint8_t* m = (uint8_t*)malloc(n);
+    for (int i = 0; i < 2 * n; ++i) { src[i] = srcf[i]; dst[i] = dstf[i]; }
+    int ok = 0;
+    double best[9];
+    if (n == 4) {
+        ok = mode ? eo_dlt_homography_cv(src, dst, 0, 4, best) : eo_dlt_homography(src, dst, 0, 4, best);
+        for (int i = 0; i < n; ++i) mask[i] = 1;
+    } else if (method == 8) {
+        uint64_t rng = 0xffffffffffffffffULL;
+        int niters = max_iters, max_good = 0;
+        const float t2 = (float)(thresh * thresh);
+        for (int iter = 0; iter < niters; ++iter) {
+            int idx[4];
+            if (!eo_get_subset4(src, dst, n, &rng, idx)) { if (iter == 0) { ok = 0; goto done; } break; }
+            double Hc[9];
+            if (!eo_dlt_homography_cv(src, dst, idx, 4, Hc)) continue;
+            eo_reproj_err(src, dst, n, Hc, err);
+            int good = 0;
+            for (int i = 0; i < n; ++i) { m[i] = err[i] <= t2; good += m[i]; }
+            if (good > (max_good > 3 ? max_good : 3)) {
+                memcpy(mask, m, n); memcpy(best, Hc, sizeof(best));
+                max_good = good;
+                niters = eo_ransac_update_iters(confidence, (double)(n - good) / n, 4, niters);
+            }
+        }
+        ok = max_good > 0;
+    } else {                                               /* LMEDS */
+        uint64_t rng = 0xffffffffffffffffULL;
+        int niters = eo_ransac_update_iters(confidence, 0.45, 4, max_iters);
+        double min_median = 1.7976931348623157e308;
+        for (int iter = 0; iter < niters; ++iter) {
+            int idx[4];
+            if (!eo_get_subset4(src, dst, n, &rng, idx)) { if (iter == 0) { ok = 0; goto done; } break; }
+            double Hc[9];
+            const int got = mode ? eo_dlt_homography_cv(src, dst, idx, 4, Hc) : eo_h4_homography(src, dst, idx, Hc);
+            if (!got) continue;
+            eo_reproj_err(src, dst, n, Hc, err);
+            memcpy(srt, err, sizeof(float) * n);
+            qsort(srt, n, sizeof(float), eo_cmp_float);
+            const double median = n % 2 != 0 ? srt[n / 2] : (srt[n / 2 - 1] + srt[n / 2]) * 0.5;
+            if (median < min_median) { min_median = median; memcpy(best, Hc, sizeof(best)); ok = 1; }
+        }
+        if (ok) {
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 4)) * sqrt(min_median);
+            sigma = sigma > 0.001 ? sigma : 0.001;
+            eo_reproj_err(src, dst, n, best, err);
+            int good = 0;
+            for (int i = 0; i < n; ++i) { mask[i] = err[i] <= (float)(sigma * sigma); good += mask[i]; }
+            ok = good >= 4;
+        }
+    }
+    if (ok && n > 4) {
+        int* sel = (int*)malloc(sizeof(int) * n); int ni = 0;
+        for (int i = 0; i < n; ++i) if (mask[i]) sel[ni++] = i;
+        double* s2 = (double*)malloc(sizeof(double) * 2 * ni); double* d2 = (double*)malloc(sizeof(double) * 2 * ni);
+        for (int i = 0; i < ni; ++i) { s2[2 * i] = src[2 * sel[i]]; s2[2 * i + 1] = src[2 * sel[i] + 1]; d2[2 * i] = dst[2 * sel[i]]; d2[2 * i + 1] = dst[2 * sel[i] + 1]; }
+        double Hr[9];
+        if (mode ? eo_dlt_homography_cv(s2, d2, 0, ni, Hr) : eo_dlt_homography(s2, d2, 0, ni, Hr)) {
+            memcpy(best, Hr, sizeof(best));
+            if (refine_iters > 0) eo_lm_refine(s2, d2, ni, best, refine_iters);
+        }
+        free(sel); free(s2); free(d2);
+    }
+done:
+    if (ok) memcpy(H, best, sizeof(best));
+    free(src); free(dst); free(err); free(srt); free(m);
+    return ok;
+}
+
 /* cv2.perspectiveTransform (coordinate_model.py:383,400-403): double compute, float store */
 void eo_perspective_transform(const float* pts, int n, const double* H, float* out)
 {

@@ -139,6 +139,8 @@ def loop_records(frames, fps, num_homography, num_keypoint_detection, detect_key
                 compute_homography = True
             else:
                 Hn, mask = P.find_homography_ransac(img_pts, world_pts, 5.0)
+                if Hn is None:                                          # cm.py:354-357: RHO is not restated, LMEDS is
+                    Hn, mask = P.find_homography(img_pts, world_pts, 4)
                 if Hn is not None:
                     prev_keypoints = {k: v for k, v, m in zip(used, img_pts.tolist(), mask.flatten()) if m}
                     H, compute_homography = Hn, False

@@ -269,7 +269,9 @@ def solve_homography(keypoints):
     img_pts, world_pts, used = select_plane_points(keypoints)
     if len(img_pts) < 4:
         return None, keypoints
-    H, mask = P.find_homography_ransac(img_pts, world_pts, 5.0)
+    H, mask = P.find_homography_ransac(img_pts, world_pts, 5.0)          # cm.py:354-357: cv2.RANSAC ...
+    if H is None:
+        H, mask = P.find_homography(img_pts, world_pts, 4)               # ... (cv2.RHO not restated: "no model") ... cv2.LMEDS
     if H is None:
         return None, keypoints
     kept = {k: v for k, v, m in zip(used, img_pts.tolist(), mask.flatten()) if m}

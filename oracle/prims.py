@@ -128,6 +128,19 @@ def dlt_homography(src, dst):
     return H.reshape(3, 3) if ok else None
 
 
+def find_homography(src, dst, method=8, thresh=5.0, max_iters=2000, confidence=0.995, refine_iters=10, cv_solver=False):
+    """cv2.findHomography(src, dst, method, thresh): method 8 = cv2.RANSAC, 4 = cv2.LMEDS.  cv_solver=True: OpenCV's own minimal solver
+    and Jacobi (the second CPU mode of eo_prims.c) instead of the production deviations.  -> (H float64 3x3, mask uint8 [n,1]) | (None, None)"""
+    src = _f32(src).reshape(-1, 2); dst = _f32(dst).reshape(-1, 2)
+    n = src.shape[0]
+    H = np.zeros(9, np.float64); mask = np.zeros(max(n, 1), np.uint8)
+    f = lib().eo_find_homography_ex
+    f.restype = C.c_int
+    ok = f(_p(src), _p(dst), n, int(method), C.c_double(thresh), int(max_iters), C.c_double(confidence), int(refine_iters), int(bool(cv_solver)),
+           _p(H, C.c_double), mask.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return (H.reshape(3, 3), mask[:n].reshape(-1, 1)) if ok else (None, None)
+
+
 def find_homography_ransac(src, dst, thresh=5.0, max_iters=2000, confidence=0.995, refine_iters=10):
     """cv2.findHomography(src, dst, cv2.RANSAC, thresh) restatement -> (H float64 3x3 | None, mask u8 [n] | None)"""
     src = _f32(src).reshape(-1, 2)

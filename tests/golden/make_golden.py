@@ -88,9 +88,14 @@ def install_stubs():
         *P.calc_optical_flow_pyr_lk(prev, cur, pts, maxLevel, criteria[1], criteria[2]), None)
 
     def find_h(src, dst, method, thr=None):
-        if method != 8:
+        # cm.py:354-357 tries cv2.RANSAC (8), cv2.RHO (16), cv2.LMEDS (4) in turn.  RANSAC and LMEDS are served by the oracle's
+        # restatements; RHO (PROSAC + SPRT, not restated) reports "no model", which hands over to LMEDS like a failed RHO does.
+        if method == 8:
+            H, mask = P.find_homography(src, dst, 8, 5.0 if thr is None else thr)
+        elif method == 4:
+            H, mask = P.find_homography(src, dst, 4)
+        else:
             return None, None
-        H, mask = P.find_homography_ransac(src, dst, 5.0 if thr is None else thr)
         return (H, mask.reshape(-1, 1)) if H is not None else (None, None)
 
     cv2.findHomography = find_h

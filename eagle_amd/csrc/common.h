@@ -52,6 +52,7 @@ struct ConvConfig {          // tile configuration chosen per layer at graph-bui
     int cin = 0, cout_pad = 0;
     int variant = 0;         // fp16 only: 0 = register-staged, 1 = persistent LDS-DMA pipeline
 };
+struct ArgmaxPart { float score; int idx; };
 struct ConvLaunch {
     ConvConfig cfg;
     TView x, y, r1, r2;      // r1/r2 optional (p == nullptr)
@@ -60,7 +61,13 @@ struct ConvLaunch {
     int pre_act = 0, post_act = 0;
     int out_f32 = 0;         // store fp32 regardless of precision (logits)
     double flop = 0;         // algorithmic 2*MAC (unpadded)
+    // fp16 family, head convolution: instead of storing the logits, every workgroup reduces sigmoid(logit) of its tile to one
+    // (maximum, first index) per channel and writes it to (*am_slot)[(frame * tiles + tile) * cout_pad + channel] (K5 fused into the
+    // producer: the fp32 logit tensor never goes to HBM).  The slot is read when the launch is enqueued.
+    ArgmaxPart* const* am_slot = nullptr;
 };
+// output tiles per frame of a convolution with this configuration (the number of partials per channel the fused arg-max writes)
+int conv_tiles_per_frame(const ConvConfig& cfg, int ho, int wo);
 // returns false when no kernel instance exists for cfg
 bool conv_supported(int precision, const ConvConfig& cfg);
 void conv_launch(int precision, const ConvLaunch& L, hipStream_t s);
@@ -82,7 +89,6 @@ void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, c
 void maxpool5_launch(const TView& x, const TView& y, hipStream_t s);
 void upsample2_launch(const TView& x, const TView& y, hipStream_t s);
 
-struct ArgmaxPart { float score; int idx; };
 // logits: fp32 view [n,h,w,64]; parts: [n][chunks][64]
 void heat_argmax_launch(const TView& logits, ArgmaxPart* parts, int chunks, hipStream_t s);
 

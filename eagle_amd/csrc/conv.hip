@@ -38,6 +38,8 @@ struct ConvArgs {
     int wx, tiles_x, tiles_y, nchunks;
     int gy;                 // number of Cout blocks
     int xcd;                // 1: XCD-aware work order (1-D grid; each XCD owns a contiguous range of (tile, Cout-block) items)
+    ArgmaxPart* am;         // fused heat-map maxima (head convolution): partials [frame][tile][am_cs] instead of the output tensor
+    int am_cs;
     const void* zeros;      // >= 16 zero bytes in global memory (source of out-of-image pixels for unconditional loads / LDS-DMA)
     void* trash;            // >= 4 KiB of scratch global memory (target of out-of-image results for unconditional stores)
 };
@@ -78,7 +80,7 @@ constexpr unsigned OOB_OFF = 0x80000000u;
 template <int NT, int PW>
 __device__ __forceinline__ void f16_epilogue(const ConvArgs& a, f32x4 (&acc)[NT][PW], char* strip,
                                              int n, int oy0, int ox0, int nb, int wave, int q, int lx, int lane,
-                                             const u32x2 (*r1pre)[PW] = nullptr)
+                                             const u32x2 (*r1pre)[PW] = nullptr, char* smem_base = nullptr)
 {
     constexpr int BN = NT * 16, GO = BN / 8, RS = BN * 2 + 16;
     const int WX = a.wx;
@@ -131,6 +133,50 @@ __device__ __forceinline__ void f16_epilogue(const ConvArgs& a, f32x4 (&acc)[NT]
 #undef EP_ALL
 #undef EP_ACT
 #undef EP_RES
+    if (a.am) {
+        // K5 fused (KeypointModel.get_keypoints, kh.py:581-593): per channel the first maximum of sigmoid(logit) over this tile.
+        // The sigmoid is applied before the compare, as np.argmax sees it; ties go to the smaller row-major index.
+        float bs[NT * 4]; int bi[NT * 4];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float best = -1.0f; int idx = 0x7fffffff;
+#pragma unroll
+                for (int p = 0; p < PW; ++p) {
+                    if (pix[p] == OOB_OFF) continue;
+                    const float sg = d_sigmoidf(acc[tt][p][r]);
+                    const int li = (int)pix[p] - n * a.Ho * a.Wo;
+                    if (sg > best || (sg == best && li < idx)) { best = sg; idx = li; }
+                }
+                bs[tt * 4 + r] = best; bi[tt * 4 + r] = idx;
+            }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1)                   // the 16 lanes that share q hold the same channels for 16 different pixels
+#pragma unroll
+            for (int k = 0; k < NT * 4; ++k) {
+                const float ob = __shfl_xor(bs[k], m, 64); const int oi = __shfl_xor(bi[k], m, 64);
+                if (ob > bs[k] || (ob == bs[k] && oi < bi[k])) { bs[k] = ob; bi[k] = oi; }
+            }
+        ArgmaxPart* red = (ArgmaxPart*)smem_base;            // [4 waves][BN]: the operand space is free after the last MFMA
+        if (lx == 0) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ArgmaxPart v; v.score = bs[tt * 4 + r]; v.idx = bi[tt * 4 + r]; red[wave * BN + tt * 16 + q * 4 + r] = v; }
+        }
+        __syncthreads();
+        const int tid = wave * 64 + lane;
+        if (tid < BN) {
+            ArgmaxPart b = red[tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const ArgmaxPart o = red[w * BN + tid]; if (o.score > b.score || (o.score == b.score && o.idx < b.idx)) b = o; }
+            const int TH = 4 * PW / WX, TW = 16 * WX;
+            const int tile = (oy0 / TH) * a.tiles_x + ox0 / TW;
+            a.am[((size_t)n * a.tiles_x * a.tiles_y + tile) * a.am_cs + nb * BN + tid] = b;
+        }
+        return;
+    }
     if (a.out_f32) {
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
@@ -353,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(ConvArgs a)
     // epilogue (every wave is past the barrier that follows the last chunk's MFMAs, so the operand space is free)
     if (PIPE) __syncthreads();
     constexpr int RS_ = BN * 2 + 16;
-    f16_epilogue<NT, PW>(a, acc, smem + wave * (PW * 16 * RS_), n, oy0, ox0, nb, wave, q, lx, lane, RPRE ? r1pre : nullptr);
+    f16_epilogue<NT, PW>(a, acc, smem + wave * (PW * 16 * RS_), n, oy0, ox0, nb, wave, q, lx, lane, RPRE ? r1pre : nullptr, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -919,6 +965,11 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
 }
 
 size_t conv_lds_bytes(int precision, const ConvConfig& c) { return lds_bytes(precision, c); }
+int conv_tiles_per_frame(const ConvConfig& c, int ho, int wo)
+{
+    const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
+    return ((wo + tw - 1) / tw) * ((ho + th - 1) / th);
+}
 
 typedef void (*ConvKernel)(ConvArgs);
 struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
@@ -1096,6 +1147,9 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
     a.nchunks = c.cin / c.kc;
     a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
+    a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
+    if (a.am && (precision != EAGLE_PREC_F16 || conv_ws(c) || c.variant == 1 || c.variant == 5))
+        fail(EAGLE_E_NOKERNEL, "fused heat-map maxima need the generic fp16 kernel");
     if (precision == EAGLE_PREC_F16) {                      // the fp16 kernels address tensors through raw buffer descriptors with 32-bit byte offsets
         const size_t lim = (size_t)1 << 31;
         const size_t cs_out = std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0);

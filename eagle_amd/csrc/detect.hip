@@ -8,56 +8,87 @@
 namespace eagle {
 
 // ------------------------------------------------------------------------------------------------------------
-// K6: one thread per anchor.
+// K6: a workgroup decodes 64 consecutive anchors of one pyramid level of one frame.  The 64 x (64 box + 16 class) logits are
+// read with fully coalesced 16-byte loads (the anchors' rows are contiguous in the NHWC head outputs) into LDS; then one
+// thread per (anchor, box side) runs the DFL soft-max expectation over its 16 logits in the oracle's order (sequential fp32
+// sum, oracle/eo_prims.c::eo_yolo_decode_level), and one thread per anchor assembles the box and the best class.
+// Round 1's one-thread-per-anchor kernel walked 256-byte rows per lane (0.34-0.67 TB/s); rows in LDS are padded by 4 dwords
+// so that the (anchor, side) threads' ds_read_b128 are conflict-free.
 // ------------------------------------------------------------------------------------------------------------
-struct DecodeArgs { DetLevel lv[3]; int n_lv, n, nc, A; float floor_; DetScratch sc; };
+struct DecodeArgs { DetLevel lv[3]; int n_lv, n, nc, A; float floor_; DetScratch sc; int blk0[4]; };   // blk0[l]: first block of level l within a frame
+#define DEC_ANCH 64
+#define DEC_BS 68            // LDS row stride of the box logits (dwords)
+#define DEC_CS 20            // ... of the class logits
 
 __global__ __launch_bounds__(256) void yolo_decode_kernel(DecodeArgs a)
 {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= a.n * a.A) return;
-    const int f = gid / a.A, an = gid - f * a.A;
+    __shared__ __attribute__((aligned(16))) float sbox[DEC_ANCH * DEC_BS];
+    __shared__ __attribute__((aligned(16))) float scls[DEC_ANCH * DEC_CS];
+    __shared__ float sd[DEC_ANCH * 4];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.y;
     int l = 0;
-    while (l + 1 < a.n_lv && an >= a.lv[l + 1].a0) ++l;
+    while (l + 1 < a.n_lv && (int)blockIdx.x >= a.blk0[l + 1]) ++l;
     const DetLevel& L = a.lv[l];
-    const int cell = an - L.a0, gy = cell / L.gw, gx = cell - gy * L.gw;
-    const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
-    const float* bp = (const float*)L.box.p + ((size_t)f * L.gh * L.gw + cell) * L.box.cs + L.box.off;
-    float d[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float lg[16];
-        const float4* q = (const float4*)(bp + s * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const float4 v = q[i]; lg[4 * i] = v.x; lg[4 * i + 1] = v.y; lg[4 * i + 2] = v.z; lg[4 * i + 3] = v.w; }
-        float m = lg[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) m = lg[i] > m ? lg[i] : m;
-        float den = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { lg[i] = d_expf(lg[i] - m); den = den + lg[i]; }
-        float num = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) num = fmaf((float)i, lg[i] / den, num);
-        d[s] = num;
+    const int cell0 = ((int)blockIdx.x - a.blk0[l]) * DEC_ANCH, ncell = L.gh * L.gw;
+    const int na = min(DEC_ANCH, ncell - cell0);
+    {   // coalesced staging: box rows are 64 floats (box.cs == 64: the head conv owns its tensor), class rows cls.cs floats
+        const float4* bsrc = (const float4*)((const float*)L.box.p + ((size_t)f * ncell + cell0) * L.box.cs + L.box.off);
+        const int bq = L.box.cs / 4;                       // float4 per row
+        for (int e = tid; e < na * 16; e += 256) {
+            const int r = e >> 4, q = e & 15;
+            *(float4*)(sbox + r * DEC_BS + q * 4) = bsrc[r * bq + q];
+        }
+        const float4* csrc = (const float4*)((const float*)L.cls.p + ((size_t)f * ncell + cell0) * L.cls.cs + L.cls.off);
+        const int cq = L.cls.cs / 4, cn = (a.nc + 3) / 4;
+        for (int e = tid; e < na * cn; e += 256) {
+            const int r = e / cn, q = e - r * cn;
+            *(float4*)(scls + r * DEC_CS + q * 4) = csrc[r * cq + q];
+        }
     }
-    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
-    const float cx = ((x1 + x2) / 2.0f) * L.stride, cy = ((y1 + y2) / 2.0f) * L.stride;
-    const float bw = (x2 - x1) * L.stride, bh = (y2 - y1) * L.stride;
-    const float hw = bw / 2.0f, hh = bh / 2.0f;
-    const float* cp = (const float*)L.cls.p + ((size_t)f * L.gh * L.gw + cell) * L.cls.cs + L.cls.off;
-    float best = -1.f; int bj = 0;
-    for (int c = 0; c < a.nc; ++c) {
-        const float pr = d_sigmoidf(cp[c]);
-        if (pr > best) { best = pr; bj = c; }
+    __syncthreads();
+    {   // (anchor, side): DFL expectation, sequential order
+        const int r = tid >> 2, sde = tid & 3;
+        if (r < na) {
+            float lg[16];
+            const float4* q = (const float4*)(sbox + r * DEC_BS + sde * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float4 v = q[i]; lg[4 * i] = v.x; lg[4 * i + 1] = v.y; lg[4 * i + 2] = v.z; lg[4 * i + 3] = v.w; }
+            float m = lg[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = lg[i] > m ? lg[i] : m;
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { lg[i] = d_expf(lg[i] - m); den = den + lg[i]; }
+            float num = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) num = fmaf((float)i, lg[i] / den, num);
+            sd[r * 4 + sde] = num;
+        }
     }
-    const size_t o = (size_t)f * a.A + an;
-    *(float4*)(a.sc.boxes + o * 4) = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
-    a.sc.conf[o] = best;
-    a.sc.cls[o] = bj;
-    if (best > a.floor_) {
-        const int pos = atomicAdd(a.sc.count + f, 1);
-        a.sc.keys[(size_t)f * a.A + pos] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)an);
+    __syncthreads();
+    if (tid < na) {
+        const int cell = cell0 + tid, an = L.a0 + cell;
+        const int gy = cell / L.gw, gx = cell - gy * L.gw;
+        const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+        const float4 d = *(const float4*)(sd + tid * 4);
+        const float x1 = ax - d.x, y1 = ay - d.y, x2 = ax + d.z, y2 = ay + d.w;
+        const float cx = ((x1 + x2) / 2.0f) * L.stride, cy = ((y1 + y2) / 2.0f) * L.stride;
+        const float bw = (x2 - x1) * L.stride, bh = (y2 - y1) * L.stride;
+        const float hw = bw / 2.0f, hh = bh / 2.0f;
+        float best = -1.f; int bj = 0;
+        for (int c = 0; c < a.nc; ++c) {
+            const float pr = d_sigmoidf(scls[tid * DEC_CS + c]);
+            if (pr > best) { best = pr; bj = c; }
+        }
+        const size_t o = (size_t)f * a.A + an;
+        *(float4*)(a.sc.boxes + o * 4) = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+        a.sc.conf[o] = best;
+        a.sc.cls[o] = bj;
+        if (best > a.floor_) {
+            const int pos = atomicAdd(a.sc.count + f, 1);
+            a.sc.keys[(size_t)f * a.A + pos] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)an);
+        }
     }
 }
 
@@ -66,8 +97,16 @@ void yolo_decode_launch(const DetLevel* lv, int n_lv, int n, int nc, float conf_
     DecodeArgs a;
     for (int i = 0; i < n_lv; ++i) a.lv[i] = lv[i];
     a.n_lv = n_lv; a.n = n; a.nc = nc; a.A = sc.A; a.floor_ = conf_floor; a.sc = sc;
+    int nblk = 0;
+    for (int i = 0; i < n_lv; ++i) {
+        if (lv[i].box.cs % 4 || lv[i].cls.cs % 4 || lv[i].box.off % 4 || lv[i].cls.off % 4 || nc > 16 || !lv[i].box.f32 || !lv[i].cls.f32)
+            fail(EAGLE_E_INVALID, "yolo_decode: head tensors must be fp32 with 16-byte aligned rows and at most 16 classes");
+        a.blk0[i] = nblk;
+        nblk += (lv[i].gh * lv[i].gw + DEC_ANCH - 1) / DEC_ANCH;
+    }
+    a.blk0[3] = nblk;
     HIP_CHECK(hipMemsetAsync(sc.count, 0, sizeof(int) * n, s));
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3((n * sc.A + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(nblk, n), dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -824,7 +824,7 @@ __global__ __launch_bounds__(POST_T) void post_kernel(PostArgs a)
         float best = -1.f; int bi = 0;
         for (int c = 0; c < pp.hm_chunks; ++c) {
             const ArgmaxPart p = a.parts[((size_t)f * pp.hm_chunks + c) * 64 + tid];
-            if (p.score > best) { best = p.score; bi = p.idx; }
+            if (p.score > best || (p.score == best && p.idx < bi)) { best = p.score; bi = p.idx; }     // partials come from pixel ranges or 2-D tiles
         }
         S.hm_idx[tid] = bi; S.hm_score[tid] = best;
         if (tid < EAGLE_N_LANDMARKS) { R->hm_idx[tid] = bi; R->hm_score[tid] = best; }
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(64) void decode_mem_kernel(DecodeArgs a)
     float best = -1.f; int bi = 0;
     for (int c = 0; c < a.pp.hm_chunks; ++c) {
         const ArgmaxPart p = a.parts[((size_t)f * a.pp.hm_chunks + c) * 64 + tid];
-        if (p.score > best) { best = p.score; bi = p.idx; }
+        if (p.score > best || (p.score == best && p.idx < bi)) { best = p.score; bi = p.idx; }
     }
     hm_idx[tid] = bi; hm_score[tid] = best;
     __syncthreads();

@@ -168,7 +168,9 @@ struct EagleHandle {
     // step buffers
     TView kp_in, det_in, logits;
     LetterBox lb;
-    int hm_chunks = 64;
+    int hm_chunks = 64;                      // heat-map partials per channel and frame (fused: output tiles of the head convolution)
+    ArgmaxPart* cur_parts = nullptr;         // where the head convolution of the step being enqueued writes its partials (fused K5)
+    bool fused_argmax = false;
     DetScratch ds;
     DetLevel levels[3];
     PostParams pp;
@@ -236,7 +238,7 @@ struct Builder {
 
     // conv (+ folded BN when bn != ""), output into `out` if given (a slice of a concat buffer), else a new tensor.
     TView conv(const TView& x, const std::string& cname, const std::string& bn, int stride, int pre, const TView* r1,
-               const TView* r2, int post, const TView* out = nullptr, bool out_f32 = false)
+               const TView* r2, int post, const TView* out = nullptr, bool out_f32 = false, ArgmaxPart* const* am_slot = nullptr)
     {
         const HostTensor& w = W(cname + ".weight");
         if (w.shape.size() != 4) fail(EAGLE_E_INVALID, "%s.weight: expected 4-d", cname.c_str());
@@ -285,6 +287,8 @@ struct Builder {
         if (r1) L.r1 = *r1;
         if (r2) L.r2 = *r2;
         L.pre_act = pre; L.post_act = post; L.out_f32 = out_f32 ? 1 : 0;
+        L.am_slot = am_slot;
+        if (am_slot) { H->hm_chunks = conv_tiles_per_frame(L.cfg, ho, wo); H->fused_argmax = true; }
         L.flop = 2.0 * N * ho * wo * (double)cout * cin * ks * ks;
         const int pr = prec;
         Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = "conv"; op.stream = cur_stream;
@@ -402,7 +406,10 @@ static TView build_hrnet(Builder& B, const TView& x_in)
     ys = hr_stage(B, ys, 3, 4, 3, false);
     ys.push_back(B.conv(ys.back(), P + "transition3.3.0.0", P + "transition3.3.0.1", 2, 0, nullptr, nullptr, R));
     ys = hr_stage(B, ys, 4, 3, 4, true);
-    TView logits = B.conv(ys[0], "unnormalized_model.1", "", 1, 0, nullptr, nullptr, 0, nullptr, true);
+    // fp16 family: sigmoid + per-tile maxima ride in the head convolution's epilogue (no logit tensor in HBM); the exact family
+    // keeps the fp32 logits and heat_argmax_kernel
+    ArgmaxPart* const* am = (B.prec == EAGLE_PREC_F16 && !getenv("EAGLE_NO_FUSED_ARGMAX")) ? &B.H->cur_parts : nullptr;
+    TView logits = B.conv(ys[0], "unnormalized_model.1", "", 1, 0, nullptr, nullptr, 0, nullptr, true, am);
     B.release(ys[0]);
     return logits;
 }
@@ -604,8 +611,9 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
         timed(h, "nms", (double)B * h->ds.A * 8.0, sd, [&] { nms_launch(h->ds, B, h->pp, sb.d_out, sd); });      // the key array, read once
     }
     if (two) HIP_CHECK(hipEventRecord(h->ev_det, sd));
+    h->cur_parts = sb.parts;
     if (!(g_dbg_skip & 1)) run_net(h, h->hr.get(), h->s_main, ev_i);     // keypoint branch
-    if (!(g_dbg_skip & 32))
+    if (!(g_dbg_skip & 32) && !h->fused_argmax)
         timed(h, "heat_argmax", (double)h->logits.n * h->logits.h * h->logits.w * h->logits.cs * 4.0, h->s_main, [&] { heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main); });
     if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));     // join
 }
@@ -808,8 +816,9 @@ static void clip_detect_keypoints(EagleHandle* h, int first, int stride, int cou
             src = sb.d_frames;
         }
         preprocess_launch(h->prec, src, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_main, 1);
+        h->cur_parts = sb.parts;
         run_net(h, h->hr.get(), h->s_main, ev_i);
-        heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
+        if (!h->fused_argmax) heat_argmax_launch(h->logits, sb.parts, h->hm_chunks, h->s_main);
         decode_mem_launch(sb.parts, na, h->pp, c.mem, first + k0 * stride, stride, h->s_main);
     }
     h->prof = prof;

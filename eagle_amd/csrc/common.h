@@ -142,6 +142,11 @@ struct ChainState {
 };
 void gray_pyramid_launch(const uint8_t* d_bgr, int n, int h, int w, uint8_t* g0, uint8_t* g1, uint8_t* g2, hipStream_t s);
 void lk_launch(const ClipView& cv, int src_frame, int dst_frame, ChainState* st, const MemList* mem, int kint, hipStream_t s);
+// ---- track identities (tracker.hip; host side of the library) ----------------------------------------------------------------
+struct Tracker;
+Tracker* tracker_create(const EagleTrackParams* p);
+void tracker_destroy(Tracker* t);
+bool tracker_apply(Tracker* t, EagleFrameResult* rec, int frame_h, int frame_w, double detector_conf);   // true: the record's persons are now keyed by track id
 int lk_debug(const char* key, long long value, void* out, long long out_bytes);   // developer diagnostics behind eagle_debug
 // heat-map maxima of `n` frames -> mem[first + k*stride] (threshold / pixel mapping / dedup, cm.py:231-251, 500-518)
 void decode_mem_launch(const ArgmaxPart* parts, int n, const PostParams& pp, MemList* mem, int first, int stride, hipStream_t s);

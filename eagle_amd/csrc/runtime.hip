@@ -164,6 +164,7 @@ struct EagleHandle {
         const uint8_t* g_src = nullptr; int g_n = 0;
     } sb[2];
     std::unique_ptr<Net> hr, yo, misc;
+    eagle::Tracker* tracker = nullptr;       // K14 state of the clip being tracked (eagle_track_*)
     std::unique_ptr<CopyPool> pool;          // host-side copy workers (eagle_process_frames from pageable memory)
     // step buffers
     TView kp_in, det_in, logits;
@@ -940,6 +941,7 @@ void eagle_destroy(EagleHandle* h)
 {
     if (h && h->clip.open) { (void)hipSetDevice(h->cfg.device); eagle::clip_close(h); }
     if (!h) return;
+    if (h->tracker) eagle::tracker_destroy(h->tracker);
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto& sb : h->sb) {
@@ -1090,6 +1092,38 @@ int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double*
     reproject_launch(d_r, d_H, d_f, n, h->cfg.frame_h, h->cfg.frame_w, h->s_main);
     HIP_CHECK(hipMemcpyAsync(recs, d_r, sizeof(EagleFrameResult) * (size_t)n, hipMemcpyDeviceToHost, h->s_main));
     HIP_CHECK(hipStreamSynchronize(h->s_main));
+    API_END(h)
+}
+
+int eagle_track_open(EagleHandle* h, const EagleTrackParams* params)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (h->tracker) eagle::tracker_destroy(h->tracker);
+    h->tracker = eagle::tracker_create(params);
+    API_END(h)
+}
+
+int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!recs || n < 0) fail(EAGLE_E_INVALID, "bad argument");
+    if (!h->tracker) fail(EAGLE_E_STATE, "eagle_track_open has not been called");
+    if (n == 0) return EAGLE_OK;
+    std::vector<double> Hs((size_t)n * 9, 0.0);
+    std::vector<uint8_t> flags((size_t)n, 0);
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        if (!eagle::tracker_apply(h->tracker, recs + i, h->cfg.frame_h, h->cfg.frame_w, h->cfg.detector_conf)) continue;
+        any = true;
+        flags[i] = recs[i].H_valid ? 1 : 2;                  // re-project the moved foot points with the frame's own homography
+        memcpy(&Hs[(size_t)i * 9], recs[i].H, sizeof(double) * 9);
+    }
+    if (any) {
+        const int rc = eagle_reproject(h, recs, n, Hs.data(), flags.data());
+        if (rc) return rc;
+    }
     API_END(h)
 }
 

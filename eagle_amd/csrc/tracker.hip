@@ -1,0 +1,293 @@
+// K14 — track identities: what the reference gets from boxmot's BotSort behind `self.tracker.update(dets, frame)`
+// (eagle/models/coordinate_model.py:66-72, 574-596).  BoT-SORT's motion / IoU association (Aharon et al. 2022, on ByteTrack's two-stage
+// scheme): constant-velocity Kalman filter on (cx, cy, w, h), high / low confidence detection sets, three linear assignments with cost
+// limits, track life cycle.  Stated deviations from the reference's configuration: appearance ReID (OSNet) and ECC camera-motion
+// compensation are off; the same restatement is oracle/tracker.py, which the tests compare this code with.
+//
+// Why this stage runs on the HOST side of the library (native C++, not a kernel): it is a strictly sequential recurrence over the
+// frames of a clip on <= 300 boxes — per frame a handful of 8x8 Kalman updates and one ~30x30 assignment, tens of microseconds on
+// one core, latency-bound.  A single workgroup would need milliseconds per frame for the same dependent chain (the reference runs it
+// on the CPU as well).  It consumes the detection records the GPU produced and hands the smoothed boxes back to the GPU for the
+// projection (eagle_reproject's kernel).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+
+namespace eagle {
+
+namespace {
+constexpr double STD_POS = 1.0 / 20, STD_VEL = 1.0 / 160;
+enum { T_NEW = 0, T_TRACKED = 1, T_LOST = 2, T_REMOVED = 3 };
+
+struct Track {
+    double z[4];                 // the detection that created / last updated it: cx, cy, w, h
+    double mean[8], cov[8][8];
+    bool has_state = false;
+    float conf = 0; int cls = 0, det_ind = -1;
+    int state = T_NEW, id = -1, frame_id = 0, start_frame = 0;
+    bool is_activated = false;
+    void xyxy(double* b) const
+    {
+        const double* c = has_state ? mean : z;
+        b[0] = c[0] - c[2] / 2; b[1] = c[1] - c[3] / 2; b[2] = c[0] + c[2] / 2; b[3] = c[1] + c[3] / 2;
+    }
+};
+using TP = std::shared_ptr<Track>;
+
+void kf_initiate(Track& t)
+{
+    for (int i = 0; i < 4; ++i) { t.mean[i] = t.z[i]; t.mean[4 + i] = 0; }
+    const double w = t.z[2], h = t.z[3];
+    const double sd[8] = {2 * STD_POS * w, 2 * STD_POS * h, 2 * STD_POS * w, 2 * STD_POS * h, 10 * STD_VEL * w, 10 * STD_VEL * h, 10 * STD_VEL * w, 10 * STD_VEL * h};
+    memset(t.cov, 0, sizeof(t.cov));
+    for (int i = 0; i < 8; ++i) t.cov[i][i] = sd[i] * sd[i];
+    t.has_state = true;
+}
+void kf_predict(Track& t)
+{
+    const double w = t.mean[2], h = t.mean[3];
+    const double sd[8] = {STD_POS * w, STD_POS * h, STD_POS * w, STD_POS * h, STD_VEL * w, STD_VEL * h, STD_VEL * w, STD_VEL * h};
+    for (int i = 0; i < 4; ++i) t.mean[i] += t.mean[4 + i];
+    // F P F^T with F = [[I, I], [0, I]]
+    double A[8][8];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) A[i][j] = t.cov[i][j] + (i < 4 ? t.cov[i + 4][j] : 0.0);
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) t.cov[i][j] = A[i][j] + (j < 4 ? A[i][j + 4] : 0.0);
+    for (int i = 0; i < 8; ++i) t.cov[i][i] += sd[i] * sd[i];
+}
+void kf_update(Track& t, const double* z)
+{
+    const double w = t.mean[2], h = t.mean[3];
+    const double sd[4] = {STD_POS * w, STD_POS * h, STD_POS * w, STD_POS * h};
+    double S[4][4], y[4];
+    for (int i = 0; i < 4; ++i) {
+        y[i] = z[i] - t.mean[i];
+        for (int j = 0; j < 4; ++j) S[i][j] = t.cov[i][j] + (i == j ? sd[i] * sd[i] : 0.0);
+    }
+    // K = P H^T S^-1 (8x4): solve S X = (P H^T)^T by Gaussian elimination with partial pivoting
+    double M[4][12];
+    for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) M[i][j] = S[i][j]; for (int k = 0; k < 8; ++k) M[i][4 + k] = t.cov[k][i]; }
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+        if (p != c) for (int j = 0; j < 12; ++j) std::swap(M[c][j], M[p][j]);
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c] / M[c][c];
+            for (int j = c; j < 12; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    double K[8][4];
+    for (int k = 0; k < 8; ++k) for (int i = 0; i < 4; ++i) K[k][i] = M[i][4 + k] / M[i][i];
+    for (int k = 0; k < 8; ++k) { double s = 0; for (int i = 0; i < 4; ++i) s += K[k][i] * y[i]; t.mean[k] += s; }
+    double KS[8][4];
+    for (int k = 0; k < 8; ++k) for (int j = 0; j < 4; ++j) { double s = 0; for (int i = 0; i < 4; ++i) s += K[k][i] * S[i][j]; KS[k][j] = s; }
+    for (int a = 0; a < 8; ++a) for (int b = 0; b < 8; ++b) { double s = 0; for (int j = 0; j < 4; ++j) s += KS[a][j] * K[b][j]; t.cov[a][b] -= s; }
+}
+
+double iou_cost(const Track& a, const Track& b)
+{
+    double p[4], q[4];
+    a.xyxy(p); b.xyxy(q);
+    const double iw = std::min(p[2], q[2]) - std::max(p[0], q[0]), ih = std::min(p[3], q[3]) - std::max(p[1], q[1]);
+    if (!(iw > 0 && ih > 0)) return 1.0;
+    const double inter = iw * ih;
+    return 1.0 - inter / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - inter);
+}
+
+// Minimum-cost assignment of an n x n matrix (Hungarian algorithm with potentials, O(n^3)); col_of[row].
+void hungarian(const std::vector<double>& a, int n, std::vector<int>& col_of)
+{
+    const double INF = 1e300;
+    std::vector<double> u(n + 1, 0), v(n + 1, 0), minv(n + 1);
+    std::vector<int> p(n + 1, 0), way(n + 1, 0);
+    std::vector<char> used(n + 1);
+    for (int i = 1; i <= n; ++i) {
+        p[0] = i;
+        int j0 = 0;
+        std::fill(minv.begin(), minv.end(), INF);
+        std::fill(used.begin(), used.end(), 0);
+        do {
+            used[j0] = 1;
+            const int i0 = p[j0];
+            double delta = INF; int j1 = 0;
+            for (int j = 1; j <= n; ++j) {
+                if (used[j]) continue;
+                const double cur = a[(size_t)(i0 - 1) * n + (j - 1)] - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+            }
+            for (int j = 0; j <= n; ++j) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (p[j0] != 0);
+        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0);
+    }
+    col_of.assign(n, -1);
+    for (int j = 1; j <= n; ++j) if (p[j]) col_of[p[j] - 1] = j - 1;
+}
+
+// lap.lapjv(cost, extend_cost=True, cost_limit=thresh): leaving a row and a column unmatched costs thresh (thresh / 2 each)
+void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thresh, std::vector<std::pair<int, int>>& m, std::vector<int>& ur, std::vector<int>& uc)
+{
+    m.clear(); ur.clear(); uc.clear();
+    const int n = (int)rows.size(), k = (int)cols.size();
+    if (n == 0 || k == 0) { for (int i = 0; i < n; ++i) ur.push_back(i); for (int j = 0; j < k; ++j) uc.push_back(j); return; }
+    const int N = n + k;
+    std::vector<double> ext((size_t)N * N, thresh / 2.0);
+    for (int i = n; i < N; ++i) for (int j = k; j < N; ++j) ext[(size_t)i * N + j] = 0.0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < k; ++j) ext[(size_t)i * N + j] = iou_cost(*rows[i], *cols[j]);
+    std::vector<int> col_of;
+    hungarian(ext, N, col_of);
+    std::vector<char> cm(k, 0);
+    for (int i = 0; i < n; ++i) {
+        if (col_of[i] >= 0 && col_of[i] < k) { m.push_back({i, col_of[i]}); cm[col_of[i]] = 1; }
+        else ur.push_back(i);
+    }
+    for (int j = 0; j < k; ++j) if (!cm[j]) uc.push_back(j);
+}
+
+bool contains(const std::vector<TP>& v, const TP& t) { return std::find(v.begin(), v.end(), t) != v.end(); }
+}  // namespace
+
+struct Tracker {
+    double hi = 0.5, lo = 0.1, newt = 0.6, match = 0.8;
+    int max_time_lost = 30;
+    int frame_id = 0, next_id = 1;
+    std::vector<TP> tracked, lost, removed;
+
+    void update_track(Track& t, const Track& d)
+    {
+        kf_update(t, d.z);
+        t.state = T_TRACKED; t.is_activated = true; t.frame_id = frame_id;
+        t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
+    }
+    // dets: x1,y1,x2,y2,conf,cls rows -> the activated tracked tracks
+    void update(const EagleDet* dets, int n, std::vector<TP>& out)
+    {
+        ++frame_id;
+        std::vector<TP> first, second;
+        for (int i = 0; i < n; ++i) {
+            const EagleDet& d = dets[i];
+            const double c = d.conf;
+            if (!(c > hi) && !(c > lo && c < hi)) continue;
+            TP t = std::make_shared<Track>();
+            const double x1 = d.x1, y1 = d.y1, x2 = d.x2, y2 = d.y2;
+            t->z[0] = (x1 + x2) / 2; t->z[1] = (y1 + y2) / 2; t->z[2] = x2 - x1; t->z[3] = y2 - y1;
+            t->conf = d.conf; t->cls = d.cls; t->det_ind = i;
+            (c > hi ? first : second).push_back(t);
+        }
+        std::vector<TP> unconfirmed, act, pool;
+        for (auto& t : tracked) (t->is_activated ? act : unconfirmed).push_back(t);
+        pool = act;
+        for (auto& t : lost) if (!contains(pool, t)) pool.push_back(t);
+        for (auto& t : pool) {
+            if (t->state != T_TRACKED) { t->mean[6] = 0; t->mean[7] = 0; }
+            kf_predict(*t);
+        }
+        std::vector<TP> activated, refind, lost_now, removed_now;
+        std::vector<std::pair<int, int>> m; std::vector<int> ur, uc;
+        assign(pool, first, match, m, ur, uc);
+        for (auto& ij : m) {
+            TP& t = pool[ij.first];
+            (t->state == T_TRACKED ? activated : refind).push_back(t);
+            update_track(*t, *first[ij.second]);
+        }
+        std::vector<TP> r_tracked;
+        for (int i : ur) if (pool[i]->state == T_TRACKED) r_tracked.push_back(pool[i]);
+        std::vector<TP> rest;
+        for (int j : uc) rest.push_back(first[j]);
+        std::vector<int> ur2, uc2;
+        assign(r_tracked, second, 0.5, m, ur2, uc2);
+        for (auto& ij : m) {
+            TP& t = r_tracked[ij.first];
+            (t->state == T_TRACKED ? activated : refind).push_back(t);
+            update_track(*t, *second[ij.second]);
+        }
+        for (int i : ur2) { r_tracked[i]->state = T_LOST; lost_now.push_back(r_tracked[i]); }
+        std::vector<int> ur3, uc3;
+        assign(unconfirmed, rest, 0.7, m, ur3, uc3);
+        for (auto& ij : m) { update_track(*unconfirmed[ij.first], *rest[ij.second]); activated.push_back(unconfirmed[ij.first]); }
+        for (int i : ur3) { unconfirmed[i]->state = T_REMOVED; removed_now.push_back(unconfirmed[i]); }
+        for (int j : uc3) {
+            TP& t = rest[j];
+            if (!((double)t->conf >= newt)) continue;
+            kf_initiate(*t);
+            t->id = next_id++;
+            t->state = T_TRACKED; t->is_activated = frame_id == 1;
+            t->frame_id = t->start_frame = frame_id;
+            activated.push_back(t);
+        }
+        for (auto& t : lost)
+            if (frame_id - t->frame_id > max_time_lost) { t->state = T_REMOVED; removed_now.push_back(t); }
+        std::vector<TP> nt;
+        for (auto& t : tracked) if (t->state == T_TRACKED) nt.push_back(t);
+        for (auto& t : activated) if (!contains(nt, t)) nt.push_back(t);
+        for (auto& t : refind) if (!contains(nt, t)) nt.push_back(t);
+        std::vector<TP> nl;
+        for (auto& t : lost) if (!contains(nt, t)) nl.push_back(t);
+        for (auto& t : lost_now) nl.push_back(t);
+        std::vector<TP> nl2;
+        for (auto& t : nl) if (!contains(removed, t)) nl2.push_back(t);       // (published order: this frame's removals leave on the next frame)
+        for (auto& t : removed_now) removed.push_back(t);
+        if (removed.size() > 4096) removed.erase(removed.begin(), removed.begin() + 2048);   // (old entries can never be in `lost` again)
+        // duplicates between tracked and lost: the older track stays
+        std::vector<char> da(nt.size(), 0), db(nl2.size(), 0);
+        for (size_t i = 0; i < nt.size(); ++i)
+            for (size_t j = 0; j < nl2.size(); ++j)
+                if (iou_cost(*nt[i], *nl2[j]) < 0.15) {
+                    if (nt[i]->frame_id - nt[i]->start_frame > nl2[j]->frame_id - nl2[j]->start_frame) db[j] = 1; else da[i] = 1;
+                }
+        tracked.clear(); lost.clear();
+        for (size_t i = 0; i < nt.size(); ++i) if (!da[i]) tracked.push_back(nt[i]);
+        for (size_t j = 0; j < nl2.size(); ++j) if (!db[j]) lost.push_back(nl2[j]);
+        out.clear();
+        for (auto& t : tracked) if (t->is_activated) out.push_back(t);
+    }
+};
+
+Tracker* tracker_create(const EagleTrackParams* p)
+{
+    Tracker* t = new Tracker;
+    if (p) {
+        t->hi = p->track_high_thresh; t->lo = p->track_low_thresh; t->newt = p->new_track_thresh; t->match = p->match_thresh;
+        t->max_time_lost = (int)(p->frame_rate / 30.0 * p->track_buffer);
+    }
+    return t;
+}
+void tracker_destroy(Tracker* t) { delete t; }
+
+// cm.py:577-616 on one record: track rows -> Player / Goalkeeper entries keyed by track id (smoothed boxes); when the tracker reports
+// no player at all the reference falls back to the raw detections keyed by detection index — which is what the record already holds.
+bool tracker_apply(Tracker* T, EagleFrameResult* R, int frame_h, int frame_w, double detector_conf)
+{
+    std::vector<TP> out;
+    const int n = std::max(0, std::min(R->n_det, EAGLE_MAX_DET));
+    T->update(R->det, n, out);
+    int persons = 0;
+    for (auto& t : out) persons += (t->cls == 0 || t->cls == 1) && !((double)t->conf < detector_conf);
+    if (persons == 0) return false;
+    for (int i = 0; i < n; ++i)
+        if (R->det[i].cls == 0 || R->det[i].cls == 1) { R->det[i].reported = 0; R->det[i].id = -1; }
+    for (auto& t : out) {
+        if (!(t->cls == 0 || t->cls == 1) || (double)t->conf < detector_conf) continue;
+        double b[4];
+        t->xyxy(b);
+        EagleDet& d = R->det[t->det_ind];
+        auto clipi = [](double v, int hi) { return (int)std::min(std::max(v, 0.0), (double)hi); };
+        d.bx1 = clipi(b[0], frame_w - 1); d.by1 = clipi(b[1], frame_h - 1); d.bx2 = clipi(b[2], frame_w - 1); d.by2 = clipi(b[3], frame_h - 1);
+        d.foot_x = (int)((d.bx1 + d.bx2) / 2.0); d.foot_y = d.by2;
+        d.id = t->id; d.reported = 1;
+        d.conf = t->conf;
+    }
+    return true;
+}
+
+}  // namespace eagle

@@ -33,6 +33,11 @@ class EagleTimings(C.Structure):
                 ("n_conv_launches", C.c_int32), ("conv_flop", C.c_double), ("reserved", C.c_int32 * 8)]
 
 
+class EagleTrackParams(C.Structure):
+    _fields_ = [("track_high_thresh", C.c_float), ("track_low_thresh", C.c_float), ("new_track_thresh", C.c_float), ("match_thresh", C.c_float),
+                ("track_buffer", C.c_int32), ("frame_rate", C.c_int32)]
+
+
 class EagleKernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms", C.c_float), ("launches", C.c_int32), ("bytes", C.c_double)]
 
@@ -101,6 +106,8 @@ def load():
     L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
     L.eagle_op_find_homography.argtypes = [i32, fp, fp, i32, C.c_double, i32, i32, dp, u8p, C.POINTER(i32)]
     L.eagle_debug.argtypes = [C.c_char_p, i64, vp, i64]
+    L.eagle_track_open.argtypes = [vp, C.POINTER(EagleTrackParams)]
+    L.eagle_track_frames.argtypes = [vp, vp, i32]
     _lib = L
     return L
 
@@ -110,7 +117,7 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
-           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug"]
+           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames"]
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
 E_REFERENCE_RAISES = -7
@@ -281,6 +288,21 @@ class Handle:
         out = np.zeros(n, RESULT_DTYPE)
         self._check(self.L.eagle_clip_fetch(self._h, out.ctypes.data_as(C.c_void_p)), "clip_fetch")
         return out
+
+    # --- track identities (include/eagle.h, eagle_track_*) -------------------------------------------------
+    def track_open(self, **params):
+        p = None
+        if params:
+            d = dict(track_high_thresh=0.5, track_low_thresh=0.1, new_track_thresh=0.6, match_thresh=0.8, track_buffer=30, frame_rate=30)
+            d.update(params)
+            p = C.byref(EagleTrackParams(**d))
+        self._check(self.L.eagle_track_open(self._h, p), "track_open")
+
+    def track_frames(self, recs):
+        """In place: the next records of the clip being tracked (frame order)."""
+        assert recs.dtype == RESULT_DTYPE and recs.flags.c_contiguous
+        self._check(self.L.eagle_track_frames(self._h, recs.ctypes.data_as(C.c_void_p), len(recs)), "track_frames")
+        return recs
 
     def set_profiling(self, on):
         self._check(self.L.eagle_set_profiling(self._h, int(on)), "set_profiling")

@@ -171,6 +171,19 @@ int eagle_clip_fetch(EagleHandle* h, EagleFrameResult* out);
 int eagle_clip_close(EagleHandle* h);
 #define EAGLE_E_REFERENCE_RAISES (-7) /* the reference raises IndexError here (calibration grid at the image border, cm.py:545) */
 
+/* ---- track identities: self.tracker.update(dets, frame) of cm.py:66-72, 574-596 -----------------------------------
+ * BoT-SORT's motion / IoU association (constant-velocity Kalman filter, high / low confidence sets, three assignments, life cycle);
+ * appearance ReID and ECC camera-motion compensation are off (stated deviations).  eagle_track_frames walks n records of ONE
+ * clip in frame order (call it chunk after chunk; eagle_track_open starts a new clip): Player / Goalkeeper entries become keyed by
+ * track id with the filter's boxes and feet (cm.py:577-596; frames on which the tracker reports no player keep the detection-index
+ * fallback of cm.py:598-616), then the pitch coordinates of the moved foot points are recomputed on the GPU with each record's H. */
+typedef struct EagleTrackParams {
+    float track_high_thresh, track_low_thresh, new_track_thresh, match_thresh;   /* 0.5, 0.1, 0.6, 0.8 (boxmot defaults) */
+    int32_t track_buffer, frame_rate;                                             /* 30, 30 */
+} EagleTrackParams;
+int eagle_track_open(EagleHandle* h, const EagleTrackParams* params /* NULL: defaults */);
+int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n);
+
 /* Frame-sharded multi-GPU: rank r owns a contiguous chunk; one RCCL all-gather of records.
  * eagle_comm_id fills a 128-byte ncclUniqueId on rank 0; the caller broadcasts it (any channel). */
 int eagle_comm_id(void* id128);

@@ -5,8 +5,10 @@ Same constructor keywords and method names as the reference: ``CoordinateModel(k
 ``get_coordinates(frames, fps, ...)`` -> ``{i: {"Coordinates", "Time", "Keypoints", "Boundaries"}}`` (cm.py:415),
 ``detect_objects(frame)``, ``detect_keypoints(frame)``.  ``get_coordinates`` covers every key-point / homography cadence of
 the reference (optical-flow propagation between detections, first-frame search, on-demand detection, calibration:
-cm.py:188-416); tracker IDs (boxmot BotSort, cm.py:577) are the remaining SURVEY §8f "next" row: IDs are the reference's
-detection-index fallback (cm.py:598-627)."""
+cm.py:188-416).  ``tracker=True`` keys Player / Goalkeeper entries by track id like the reference does through boxmot's BotSort
+(cm.py:574-596): the library's BoT-SORT motion / IoU association with ReID and camera-motion compensation off (include/eagle.h,
+eagle_track_*; stated deviations).  ``tracker=False`` (default) is the reference's detection-index fallback (cm.py:598-627), the
+stateless configuration of SURVEY §8a."""
 import numpy as np
 
 from . import clip, lib, records, weights
@@ -16,8 +18,9 @@ from .pitch import INTERSECTION_TO_PITCH_POINTS
 class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
                  detector="n", det_imgsz=640, batch=8, precision="f16", device=0, hrnet_state_dict=None,
-                 detector_state_dict=None, seed=0, use_graph=False):
+                 detector_state_dict=None, seed=0, use_graph=False, tracker=False):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
+        self.tracker = tracker
         self.batch = batch
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
                                  det_imgsz=det_imgsz, batch=batch,
@@ -40,8 +43,12 @@ class CoordinateModel:
         keypoint_interval = max(1, int(fps / max(1, num_keypoint_detection)))
         if calibration or keypoint_interval != 1:
             recs = self.flow_records(frames, keypoint_interval, homography_interval, calibration)
+            if self.tracker:
+                self._track(recs)
             return {i: records.to_reference_dict(r, i, fps, own_h=bool(r["pad"][0])) for i, r in enumerate(recs)}
         recs = self.process_records(frames)
+        if self.tracker:
+            self._track(recs)
         own = np.ones(len(recs), bool)
         if homography_interval > 1:
             # cm.py:333-367: H is solved on scheduled frames or while the retry flag is set, and carried otherwise.  Every
@@ -63,6 +70,12 @@ class CoordinateModel:
             if flags.any():
                 recs = self.handle.reproject(np.ascontiguousarray(recs), Hs, flags)
         return {i: records.to_reference_dict(r, i, fps, own_h=bool(own[i])) for i, r in enumerate(recs)}
+
+    def _track(self, recs):
+        """One clip: track ids + smoothed boxes into the records (frame order), pitch coordinates re-projected on the GPU."""
+        self.handle.track_open()
+        self.handle.track_frames(recs)
+        return recs
 
     def flow_records(self, frames, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None):
         """Records of the reference loop in a stateful cadence (cm.py:188-416); see eagle_amd/clip.py."""

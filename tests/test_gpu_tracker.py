@@ -77,4 +77,4 @@ def test_track_ids_equal_oracle(name):
                 assert abs(e[oid]["Confidence"] - g[oid]["Confidence"]) < 1e-7
                 assert e[oid]["Transformed_Coordinates"] == g[oid]["Transformed_Coordinates"], (name, i, cname, oid)
                 assert e[oid].get("Image_Bottom_center") == g[oid].get("Image_Bottom_center")
-    assert tracked_frames >= len(clip) - 2
+    assert tracked_frames >= len(clip) - 6          # ("lowconf" starts with frames on which no track is confirmed yet: the raw-detection fallback)

@@ -43,14 +43,14 @@ def usable_cpus():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(hs, ys, frames, n_frames, threads, budget_s=25.0):
+def cpu_baseline(hs, ys, frames, n_frames, threads, budget_s=25.0, variant="n", imgsz=640):
     """The oracle's torch-CPU fp32 restatement of S(frame), timed on this host on a bounded sample
     (at most n_frames frames or ~budget_s seconds of CPU work, whichever comes first)."""
     import torch
     torch.set_num_threads(threads)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle import pipeline
-    m = pipeline.OracleModel(hs, ys, backend="torch")
+    m = pipeline.OracleModel(hs, ys, variant=variant, imgsz=imgsz, backend="torch")
     t0 = time.perf_counter()
     m.step(frames[0])                                  # warm-up (weight folding, MKLDNN primitives)
     log(f"cpu_baseline warm-up frame {time.perf_counter() - t0:.1f} s ({threads} threads)")
@@ -286,7 +286,7 @@ def main():
         if pcie is not None:
             res["pcie_inclusive"] = pcie
         if not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())))
+            res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())), variant=a.detector, imgsz=a.imgsz)
             # (all 256 hardware threads of the GPU box were tried once: torch-CPU convolutions collapse to 0.004 frames/s, 247 s for one
             #  frame, profiles/r02b_bench_default_1gpu.json, so the bounded sample stays at 16 threads and says so)
     h.free(d_clip)

@@ -142,6 +142,9 @@ struct ChainState {
 };
 void gray_pyramid_launch(const uint8_t* d_bgr, int n, int h, int w, uint8_t* g0, uint8_t* g1, uint8_t* g2, hipStream_t s);
 void lk_launch(const ClipView& cv, int src_frame, int dst_frame, ChainState* st, const MemList* mem, int kint, hipStream_t s);
+// ---- team colours (teams.hip, K15) ----------------------------------------------------------------------------------------------
+void team_colors_launch(const uint8_t* d_bgr, int n_frames, int fh, int fw, const EagleCrop* d_crops, int n_crops, int* d_counts, hipStream_t s);
+
 // ---- track identities (tracker.hip; host side of the library) ----------------------------------------------------------------
 struct Tracker;
 Tracker* tracker_create(const EagleTrackParams* p);

@@ -1095,6 +1095,23 @@ int eagle_reproject(EagleHandle* h, EagleFrameResult* recs, int n, const double*
     API_END(h)
 }
 
+int eagle_team_colors(EagleHandle* h, const void* d_bgr, int n_frames, const EagleCrop* crops, int n_crops, int32_t* counts)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!d_bgr || n_frames < 0 || n_crops < 0 || (n_crops > 0 && (!crops || !counts))) fail(EAGLE_E_INVALID, "bad argument");
+    if (n_crops == 0) return EAGLE_OK;
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    Net scratch;
+    EagleCrop* d_c = (EagleCrop*)scratch.get(sizeof(EagleCrop) * (size_t)n_crops);
+    int* d_n = (int*)scratch.get(sizeof(int) * 12 * (size_t)n_crops);
+    HIP_CHECK(hipMemcpyAsync(d_c, crops, sizeof(EagleCrop) * (size_t)n_crops, hipMemcpyHostToDevice, h->s_main));
+    eagle::team_colors_launch((const uint8_t*)d_bgr, n_frames, h->cfg.frame_h, h->cfg.frame_w, d_c, n_crops, d_n, h->s_main);
+    HIP_CHECK(hipMemcpyAsync(counts, d_n, sizeof(int) * 12 * (size_t)n_crops, hipMemcpyDeviceToHost, h->s_main));
+    HIP_CHECK(hipStreamSynchronize(h->s_main));
+    API_END(h)
+}
+
 int eagle_track_open(EagleHandle* h, const EagleTrackParams* params)
 {
     if (!h) return EAGLE_E_INVALID;

@@ -106,6 +106,7 @@ def load():
     L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
     L.eagle_op_find_homography.argtypes = [i32, fp, fp, i32, C.c_double, i32, i32, dp, u8p, C.POINTER(i32)]
     L.eagle_debug.argtypes = [C.c_char_p, i64, vp, i64]
+    L.eagle_team_colors.argtypes = [vp, vp, i32, vp, i32, vp]
     L.eagle_track_open.argtypes = [vp, C.POINTER(EagleTrackParams)]
     L.eagle_track_frames.argtypes = [vp, vp, i32]
     _lib = L
@@ -117,7 +118,7 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
-           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames"]
+           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_team_colors"]
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
 E_REFERENCE_RAISES = -7
@@ -287,6 +288,13 @@ class Handle:
     def clip_fetch(self, n):
         out = np.zeros(n, RESULT_DTYPE)
         self._check(self.L.eagle_clip_fetch(self._h, out.ctypes.data_as(C.c_void_p)), "clip_fetch")
+        return out
+
+    def team_colors(self, dptr, n_frames, crops):
+        """crops: int32 [k,5] (frame, x1, y1, x2, y2) of a clip resident in HBM -> int32 [k,12] colour-range counts (include/eagle.h)."""
+        crops = np.ascontiguousarray(crops, np.int32).reshape(-1, 5)
+        out = np.zeros((len(crops), 12), np.int32)
+        self._check(self.L.eagle_team_colors(self._h, dptr, n_frames, crops.ctypes.data_as(C.c_void_p), len(crops), out.ctypes.data_as(C.c_void_p)), "team_colors")
         return out
 
     # --- track identities (include/eagle.h, eagle_track_*) -------------------------------------------------

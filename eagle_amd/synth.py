@@ -59,6 +59,32 @@ def _stamp(img, xs, ys, color, rad=1):
             img[y[m], x[m]] = color
 
 
+_PLAYER_COLOURS = np.where(np.arange(25)[:, None] < 12, np.array([[40, 40, 220]]), np.array([[220, 200, 40]]))
+_PLAYER_COLOURS[24] = (20, 20, 20)
+
+
+def player_boxes(seed, t, h=720, w=1280, _with_height=False):
+    """The rectangles frame() draws for the 25 people: [(k, x0, y0, x1, y1)], clipped to the frame (k < 12: first team, 12..23: second
+    team, 24: referee).  Ground truth for the track / team-colour tests."""
+    Hm = camera(seed, t)
+    sx, sy = w / 1280.0, h / 720.0
+    rp = np.random.Generator(np.random.PCG64([seed, 5]))
+    base = np.stack([rp.uniform(5, 100, 25), rp.uniform(4, 64, 25)], 1)
+    vel = rp.normal(0, 0.03, (25, 2))
+    feet = project(Hm, base + vel * t)
+    out = []
+    for k in range(25):
+        fx, fy = feet[k, 0] * sx, feet[k, 1] * sy
+        ph_ = int(max(18, 0.09 * fy + 8) * sy)
+        pw_ = max(6, ph_ // 3)
+        x0, x1 = int(fx - pw_ // 2), int(fx + pw_ // 2)
+        y0, y1 = int(fy - ph_), int(fy)
+        x0, x1, y0, y1 = max(x0, 0), min(x1, w), max(y0, 0), min(y1, h)
+        if x1 > x0 and y1 > y0:
+            out.append((k, x0, y0, x1, y1, ph_) if _with_height else (k, x0, y0, x1, y1))
+    return out
+
+
 def frame(seed, t, h=720, w=1280):
     r = np.random.Generator(np.random.PCG64([seed, 1000 + t]))
     yy = np.arange(h, dtype=np.int32)[:, None]
@@ -81,23 +107,9 @@ def frame(seed, t, h=720, w=1280):
     p = project(Hm, circ)
     _stamp(img, (p[:, 0] * sx).astype(np.int64), (p[:, 1] * sy).astype(np.int64), (235, 235, 235))
     # players: world positions drift smoothly; drawn as upright rectangles with the foot on the ground point
-    rp = np.random.Generator(np.random.PCG64([seed, 5]))
-    base = np.stack([rp.uniform(5, 100, 25), rp.uniform(4, 64, 25)], 1)
-    vel = rp.normal(0, 0.03, (25, 2))
-    cols = np.where(np.arange(25)[:, None] < 12, np.array([[40, 40, 220]]), np.array([[220, 200, 40]]))
-    cols[24] = (20, 20, 20)
-    pos = base + vel * t
-    feet = project(Hm, pos)
-    for k in range(25):
-        fx, fy = feet[k, 0] * sx, feet[k, 1] * sy
-        ph_ = int(max(18, 0.09 * fy + 8) * sy)
-        pw_ = max(6, ph_ // 3)
-        x0, x1 = int(fx - pw_ // 2), int(fx + pw_ // 2)
-        y0, y1 = int(fy - ph_), int(fy)
-        x0, x1, y0, y1 = max(x0, 0), min(x1, w), max(y0, 0), min(y1, h)
-        if x1 > x0 and y1 > y0:
-            img[y0:y1, x0:x1] = cols[k]
-            img[y0:min(y0 + max(3, ph_ // 6), y1), x0:x1] = (150, 170, 215)
+    for k, x0, y0, x1, y1, ph_ in player_boxes(seed, t, h, w, _with_height=True):
+        img[y0:y1, x0:x1] = _PLAYER_COLOURS[k]
+        img[y0:min(y0 + max(3, ph_ // 6), y1), x0:x1] = (150, 170, 215)
     bpos = project(Hm, np.array([[52.5 + 20 * np.sin(0.02 * t), 34.0 + 12 * np.cos(0.017 * t)]]))[0]
     by, bx = np.ogrid[-4:5, -4:5]
     disc = (by * by + bx * bx) <= 12

@@ -184,6 +184,12 @@ typedef struct EagleTrackParams {
 int eagle_track_open(EagleHandle* h, const EagleTrackParams* params /* NULL: defaults */);
 int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n);
 
+/* ---- team colours: Processor.detect_color, eagle/processor.py:466-503, for player crops of a clip resident in HBM -----
+ * counts[12 * i + k]: pixels of crop i's player cluster inside colour range k of proc.py:10-23, k = red (red2 merged), orange, yellow,
+ * green, cyan, blue, purple, magenta, white, gray, black; slot 11 = pixels of the player cluster.  Crops are frame[y1:y2, x1:x2]. */
+typedef struct EagleCrop { int32_t frame, x1, y1, x2, y2; } EagleCrop;
+int eagle_team_colors(EagleHandle* h, const void* d_bgr, int n_frames, const EagleCrop* crops, int n_crops, int32_t* counts);
+
 /* Frame-sharded multi-GPU: rank r owns a contiguous chunk; one RCCL all-gather of records.
  * eagle_comm_id fills a 128-byte ncclUniqueId on rank 0; the caller broadcasts it (any channel). */
 int eagle_comm_id(void* id128);

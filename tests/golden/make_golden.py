@@ -306,6 +306,49 @@ def dump_ingest():
     json.dump(out, open(f"{HERE}/ingest_golden.json", "w"))
 
 
+# ------------------------------------------------------------------------------------------------------------ 7
+def dump_team():
+    """Team colours: the reference's OWN Processor.get_team_mapping / detect_color (eagle/processor.py:405-503) over synthetic frames and
+    ground-truth player boxes, with cv2 replaced by numpy definitions (inRange, bitwise_and, countNonZero, BGR2RGB) and the oracle's
+    BGR2HSV restatement; scikit-learn's KMeans is the real one."""
+    import importlib.util
+    import types as _types
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import team_cases
+    cv2 = _types.ModuleType("cv2")
+    cv2.COLOR_BGR2RGB, cv2.COLOR_BGR2HSV = 4, 40
+    cv2.cvtColor = lambda img, code: P.bgr2hsv(np.ascontiguousarray(img)) if code == 40 else np.ascontiguousarray(img[..., ::-1])
+
+    def bitwise_and(a, b, mask=None):
+        out = np.bitwise_and(a, b)
+        if mask is not None:
+            out = np.where((mask != 0)[..., None] if out.ndim == 3 else (mask != 0), out, 0).astype(a.dtype)
+        return out
+    cv2.bitwise_and = bitwise_and
+    cv2.inRange = lambda img, lo, hi: (np.all((img >= lo) & (img <= hi), axis=2).astype(np.uint8) * 255)
+    cv2.countNonZero = lambda m: int(np.count_nonzero(m))
+    cv2.KalmanFilter = object
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    try:
+        spec = importlib.util.spec_from_file_location("ref_processor", os.path.join(REF, "eagle", "processor.py"))
+        proc = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(proc)
+    finally:
+        if saved is not None:
+            sys.modules["cv2"] = saved
+    frames, coords = team_cases.make_case()
+    pr = proc.Processor(coords, frames, fps=5)
+    mapping = pr.get_team_mapping()
+    crops = []
+    for i, frame in enumerate(frames):
+        for pid, it in coords[i]["Coordinates"]["Player"].items():
+            x1, y1, x2, y2 = it["BBox"]
+            crops.append({"frame": i, "player": int(pid), "bbox": it["BBox"], "colors": [[c, int(n)] for c, n in pr.detect_color(frame[y1:y2, x1:x2])]})
+    json.dump({"team_mapping": {str(k): int(v) for k, v in mapping.items()}, "crops": crops}, open(f"{HERE}/team_golden.json", "w"))
+    print("team golden:", len(crops), "crops,", mapping)
+
+
 if __name__ == "__main__":
     dump_pitch()
     dump_hrnet()
@@ -313,3 +356,4 @@ if __name__ == "__main__":
     dump_cadence()
     dump_flow()
     dump_ingest()
+    dump_team()

@@ -1,0 +1,34 @@
+"""-m gpu: team colours through the C ABI (eagle_team_colors, K15) against the reference's own outputs (tests/golden/team_golden.json:
+eagle/processor.py's get_team_mapping / detect_color run over scikit-learn's KMeans) on a clip resident in HBM."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import team_cases
+from eagle_amd import lib, teams
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "team_golden.json")))
+
+
+def test_crop_colours_and_team_mapping_equal_reference():
+    frames, coords = team_cases.make_case()
+    h = lib.Handle(batch=1)
+    d = h.upload(np.stack(frames))
+    try:
+        crops = [(c["frame"], *c["bbox"]) for c in GOLD["crops"]]
+        got = teams.crop_colors(h, d, len(frames), crops)
+        same = sum([[k, n] for k, n in g] == c["colors"] for g, c in zip(got, GOLD["crops"]))
+        top = sum((g[0][0] if g else None) == (c["colors"][0][0] if c["colors"] else None) for g, c in zip(got, GOLD["crops"]))
+        print(f"crops with identical colour counts: {same} of {len(crops)}; identical dominant colour: {top}")
+        assert top == len(crops)                         # the colour that votes is the reference's on every crop
+        assert same >= 0.95 * len(crops)                 # counts: the deterministic 2-means start reaches sklearn's partition (stated deviation otherwise)
+        m = teams.get_team_mapping(h, d, coords)
+        assert {str(k): v for k, v in m.items()} == GOLD["team_mapping"]
+        # degenerate crops do not break the kernel: empty, out of frame, single colour
+        z = h.team_colors(d, len(frames), [(0, 10, 10, 10, 40), (0, -5, 0, 20, 20), (9, 0, 0, 8, 8), (0, 0, 0, 16, 16)])
+        assert z[:3].sum() == 0 and z[3, 11] >= 0
+    finally:
+        h.free(d); h.close()

@@ -22,3 +22,15 @@ class Processor:
 
     def process_clip(self, frames):
         return [records.to_process_dict(r) for r in self.model.process_records(frames)]
+
+    def get_team_mapping(self, frames, coords):
+        """The reference post-processor's ``get_team_mapping`` (eagle/processor.py:405-464; its "pretty slow" step) for a clip and the
+        ``get_coordinates`` output of that clip: colour segmentation and counting of every player crop on the GPU (eagle_amd/teams.py).
+        -> {player_id: 0 | 1}.  Player ids are track ids when the model was built with ``tracker=True``."""
+        from . import teams
+        frames = np.ascontiguousarray(frames, np.uint8)
+        d = self.model.handle.upload(frames)
+        try:
+            return teams.get_team_mapping(self.model.handle, d, coords)
+        finally:
+            self.model.handle.free(d)

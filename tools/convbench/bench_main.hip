@@ -6,6 +6,7 @@
 #include <vector>
 #include CONV_SRC
 namespace eagle {
+void ensure_max_dynamic_lds(const void* fn, int bytes) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
 void fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); exit(1); }
 }
 using namespace eagle;

@@ -225,8 +225,15 @@ def main():
     conv_ms, conv_flop, n_conv, ktimes, prof_steps = profile(h, d_clip, B)
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # bandwidth-bound kernels: algorithmic bytes (inputs once + outputs once, counted by the library per launch) / HIP-event time
-    hbm_rows = []
-    for name, ms, launches, nbytes in ktimes:
+    hbm_rows, conv_rows = [], []
+    conv_bytes = sum(nbytes for name, _, _, nbytes, _ in ktimes if name.startswith("conv "))
+    for name, ms, launches, nbytes, flop in ktimes:
+        if name.startswith("conv ") and ms > 0:
+            us = ms * 1e3 / launches
+            conv_rows.append({"layer": name[5:], "launches_per_step": launches // prof_steps, "avg_us": round(us, 2), "ms_per_step": round(ms / prof_steps, 3),
+                              "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "frac_mfma": round(flop / (ms * 1e-3) / 1e12 / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
+                              "GBps_algorithmic": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_hbm_6p3TBps": round(nbytes / (ms * 1e-3) / 1e9 / 6300.0, 4)})
+            continue
         if nbytes > 0 and ms > 0:
             gbps = nbytes / (ms * 1e-3) / 1e9
             hbm_rows.append({"kernel": name, "launches_per_step": launches // prof_steps, "bytes_algorithmic_per_step": round(nbytes / prof_steps),
@@ -274,11 +281,14 @@ def main():
                          "frac": round(achieved / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
                          "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
                          "conv_ms_per_step": round(conv_ms / prof_steps, 3),
+                         "algorithmic_bytes_per_launch": round(conv_bytes / max(n_conv, 1)),
                          "traffic": traffic, "traffic_source": traffic_src},
             "value_is": "frames/s with the clip resident in HBM before the timed region (records land on the host inside it); pcie_inclusive.value is the same path fed from host memory",
         }
         if hbm_rows:
             res["roofline_hbm"] = hbm_rows
+        if conv_rows:      # the ten convolution layer shapes that take the most time, each against BOTH roofs (MFMA peak; 6.3 TB/s achievable HBM)
+            res["roofline_conv_layers"] = sorted(conv_rows, key=lambda r: -r["ms_per_step"])[:10]
         if exact is not None:
             res["exact_family"] = exact
         if cadence is not None:

@@ -652,182 +652,6 @@ __global__ __launch_bounds__(256, WGS) void conv_f16_ws_kernel(ConvArgs a)
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// fp16 family, variant 1: persistent workgroups + double-buffered LDS filled by LDS-DMA (global_load_lds_dwordx4).
-//   * items = (tile, Cin-chunk) pairs; while the MFMAs of item i read LDS stage i&1, the DMA of item i+1 fills the other
-//     stage: no staging registers, no ds_write, one barrier per item.
-//   * LDS activation image is pixel-major and UNPADDED ([halo pixel][KC] fp16): a DMA slab is 64 consecutive 16-byte groups in
-//     (pixel, group) order, so the global side reads runs of KC*2 contiguous bytes per pixel (as coalesced as the
-//     register-staged variant) while the LDS side is lane-linear as the DMA requires.
-//   * out-of-image halo pixels are DMA'd from a 16-byte zero page.
-// ------------------------------------------------------------------------------------------------------------
-template <int KS, int S, int KC, int NT, int PW>
-__global__ __launch_bounds__(256) void conv_f16_dma_kernel(ConvArgs a)
-{
-    constexpr int G = KC / 8;
-    constexpr int PS = KC * 2;
-    constexpr int TAPS = KS * KS;
-    constexpr int NGR = TAPS * G;
-    constexpr int NI = (NGR + 3) / 4;
-    constexpr int BN = NT * 16;
-    constexpr int WBYTES = NI * 4 * BN * 16;
-    constexpr int WSLABS = WBYTES / 1024;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int WX = a.wx, TH = 4 * PW / WX, TW = 16 * WX;
-    const int halo_w = (TW - 1) * S + KS, halo_h = (TH - 1) * S + KS;
-    const int ngroups = halo_h * halo_w * G;
-    const int aslabs = (ngroups + 63) >> 6;
-    const int stage_bytes = WBYTES + aslabs * 1024;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4, lx = lane & 15;
-    const int ntiles = a.tiles_x * a.tiles_y * a.N;
-    const int gy = a.gy;
-    const _Float16* xg = (const _Float16*)a.x;
-    const _Float16* zp = (const _Float16*)a.zeros;
-
-    int abase[PW];
-#pragma unroll
-    for (int p = 0; p < PW; ++p) {
-        const int s = wave * PW + p, row = s / WX, xb = s - row * WX;
-        abase[p] = ((row * S) * halo_w + (xb * 16 + lx) * S) * PS;
-    }
-    int koff[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int g = 4 * i + q;
-        if (g < NGR) {
-            const int tap = g / G, cg = g - tap * G, ky = tap / KS, kx = tap - ky * KS;
-            koff[i] = (ky * halo_w + kx) * PS + cg * 16;
-        } else {
-            koff[i] = 0;
-        }
-    }
-    const int wlane = (q * BN + lx) * 16;
-
-    f32x4 acc[NT][PW];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int p = 0; p < PW; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // work items of this workgroup: (tile, Cout block) pairs in XCD-contiguous order, each with nchunks chunks
-    const int nitems = ntiles * gy;
-    const int nwg = gridDim.x;
-    int item, item_end;
-    {   // the dispatcher places workgroup b on XCD b % 8: give every XCD a contiguous range of items (L2 locality only)
-        const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
-        const int per_xcd_wg = (nwg + 7 - xcd) >> 3;                       // workgroups on this XCD
-        const int qn = nitems >> 3, rn = nitems & 7;
-        const int x0 = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
-        const int xc = qn + (xcd < rn ? 1 : 0);                            // items owned by this XCD
-        const int per = (xc + per_xcd_wg - 1) / per_xcd_wg;
-        item = x0 + k * per;
-        item_end = min(x0 + xc, item + per);
-    }
-    if (item >= item_end) return;
-    int ch = 0, stage = 0;
-
-#define DMA_ITEM(IT_, t_, nb_) const int t_ = (IT_) / gy, nb_ = (IT_) - t_ * gy;
-#define DMA_TILE_ORIGIN(T_, n_, oy0_, ox0_)                  \
-    int n_, oy0_, ox0_;                                      \
-    {                                                        \
-        int tt_ = (T_);                                      \
-        const int tx_ = tt_ % a.tiles_x; tt_ /= a.tiles_x;   \
-        const int ty_ = tt_ % a.tiles_y;                     \
-        n_ = tt_ / a.tiles_y; oy0_ = ty_ * TH; ox0_ = tx_ * TW; \
-    }
-#define DMA_ISSUE(IT_, CH_, ST_)                                                                               \
-    {                                                                                                          \
-        char* sb_ = smem + (ST_) * stage_bytes;                                                                \
-        DMA_ITEM(IT_, t_i, nb_i)                                                                               \
-        const char* wsrc = (const char*)a.w + (size_t)(nb_i * a.nchunks + (CH_)) * WBYTES + lane * 16;         \
-        for (int ws = wave; ws < WSLABS; ws += 4)                                                              \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + ws * 1024), \
-                                             (__attribute__((address_space(3))) void*)(sb_ + ws * 1024), 16, 0, 0); \
-        DMA_TILE_ORIGIN(t_i, n_i, oy0_i, ox0_i)                                                                \
-        const int iy0 = oy0_i * S - KS / 2, ix0 = ox0_i * S - KS / 2;                                          \
-        const long long base = ((long long)(n_i * a.H + iy0) * a.W + ix0) * a.xcs + a.xoff + (CH_) * KC;       \
-        for (int as = wave; as < aslabs; as += 4) {                                                            \
-            const int e = as * 64 + lane;                                                                      \
-            const int pix = e / G, g = e - pix * G;                                                            \
-            const int hy = pix / halo_w, hx = pix - hy * halo_w;                                               \
-            const int iy = iy0 + hy, ix = ix0 + hx;                                                            \
-            const bool ok = e < ngroups && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                         \
-            const _Float16* src = ok ? xg + base + (long long)(hy * a.W + hx) * a.xcs + g * 8 : zp;            \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,               \
-                                             (__attribute__((address_space(3))) void*)(sb_ + WBYTES + as * 1024), 16, 0, 0); \
-        }                                                                                                      \
-    }
-
-    DMA_ISSUE(item, 0, 0)
-    for (;;) {
-        __syncthreads();                               // item i has landed (vmcnt(0)) and stage^1 is no longer being read
-        int nit = item, nch = ch + 1;
-        if (nch == a.nchunks) { nch = 0; ++nit; }
-        const bool has_next = nit < item_end;
-        if (has_next) DMA_ISSUE(nit, nch, stage ^ 1)
-        const char* lds_w = smem + stage * stage_bytes;
-        const char* lds_a = lds_w + WBYTES;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            half8 wa[NT], xb[PW];
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) wa[tt] = *(const half8*)(lds_w + wlane + i * (4 * BN * 16) + tt * 256);
-#pragma unroll
-            for (int p = 0; p < PW; ++p) xb[p] = *(const half8*)(lds_a + abase[p] + koff[i]);
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int p = 0; p < PW; ++p)
-                    acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[tt], xb[p], acc[tt][p], 0, 0, 0);
-        }
-        if (ch == a.nchunks - 1) {                     // epilogue: lane holds channels co..co+3 of pixel (oy, ox)
-            DMA_ITEM(item, t, nb)
-            DMA_TILE_ORIGIN(t, n, oy0, ox0)
-#pragma unroll
-            for (int p = 0; p < PW; ++p) {
-                const int s = wave * PW + p, row = s / WX, xb = s - row * WX;
-                const int oy = oy0 + row, ox = ox0 + xb * 16 + lx;
-                const bool inb = oy < a.Ho && ox < a.Wo;
-                const size_t pidx = (size_t)(n * a.Ho + oy) * a.Wo + ox;
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) {
-                    if (inb) {
-                        const int co = nb * BN + tt * 16 + q * 4;
-                        const float4 bv = *(const float4*)(a.bias + co);
-                        float v[4] = {acc[tt][p][0] + bv.x, acc[tt][p][1] + bv.y, acc[tt][p][2] + bv.z, acc[tt][p][3] + bv.w};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.pre_act);
-                        if (a.r1) {
-                            const half4 rv = *(const half4*)((const _Float16*)a.r1 + pidx * a.r1cs + a.r1off + co);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
-                        }
-                        if (a.r2) {
-                            const half4 rv = *(const half4*)((const _Float16*)a.r2 + pidx * a.r2cs + a.r2off + co);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = v[r] + (float)rv[r];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = d_act(v[r], a.post_act);
-                        if (a.out_f32) {
-                            *(float4*)((float*)a.y + pidx * a.ycs + a.yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-                            half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                            *(half4*)((_Float16*)a.y + pidx * a.ycs + a.yoff + co) = o;
-                        }
-                    }
-                    acc[tt][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        }
-        if (!has_next) break;
-        item = nit; ch = nch; stage ^= 1;
-    }
-#undef DMA_ISSUE
-#undef DMA_TILE_ORIGIN
-#undef DMA_ITEM
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // fp32 exact family.  KC = 16 (or 4 for the 3-channel stems); canonical K order.
@@ -944,7 +768,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvArgs a)
 static int f16_ps(int kc) { const int g = kc / 8; return kc * 2 + ((g % 2 == 0) ? 16 : 0); }
 static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
-static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 5 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
+static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
@@ -952,10 +776,6 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     const int hw = (tw - 1) * c.stride + c.ks, hh = (th - 1) * c.stride + c.ks;
     const int bn = c.nt * 16;
-    if (precision == EAGLE_PREC_F16 && (c.variant == 1 || c.variant == 5)) {
-        const size_t aslabs = ((size_t)hh * hw * (c.kc / 8) + 63) / 64;
-        return 2 * ((size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + aslabs * 1024);
-    }
     if (precision == EAGLE_PREC_F16) {
         const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)hh * hw * f16_ps(c.kc);
         const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 2 + 16);        // output transpose, one strip per wave
@@ -974,13 +794,8 @@ int conv_tiles_per_frame(const ConvConfig& c, int ho, int wo)
 typedef void (*ConvKernel)(ConvArgs);
 struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 
-// Variants 1 (LDS-DMA pipeline) and 2 (chunk-pipelined staging) lost to plain occupancy on every measured layer;
-// they are only instantiated for the autotuner (-DEAGLE_CONV_EXPERIMENTAL) to keep the library build short.
-#ifdef EAGLE_CONV_EXPERIMENTAL
-#define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}, {EAGLE_PREC_F16, KS, S, KC, NT, 1, conv_f16_dma_kernel<KS, S, KC, NT, 4>}, {EAGLE_PREC_F16, KS, S, KC, NT, 5, conv_f16_dma_kernel<KS, S, KC, NT, 2>}
-#else
+// (The LDS-DMA pipeline variants 1 / 5 lost to plain occupancy on every measured layer; they live in tools/convbench/conv_exp.hip.)
 #define I16(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4>}
-#endif
 #define I16P(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 2, conv_f16_kernel<KS, S, KC, NT, true, 4>}
 #define I16H(KS, S, KC, NT) {EAGLE_PREC_F16, KS, S, KC, NT, 3, conv_f16_kernel<KS, S, KC, NT, false, 2>}
 #define ALLNT16H(KS, S, KC) I16H(KS, S, KC, 1), I16H(KS, S, KC, 2), I16H(KS, S, KC, 3), I16H(KS, S, KC, 4), I16H(KS, S, KC, 6)
@@ -1148,7 +963,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.nchunks = c.cin / c.kc;
     a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
-    if (a.am && (precision != EAGLE_PREC_F16 || conv_ws(c) || c.variant == 1 || c.variant == 5))
+    if (a.am && (precision != EAGLE_PREC_F16 || conv_ws(c)))
         fail(EAGLE_E_NOKERNEL, "fused heat-map maxima need the generic fp16 kernel");
     if (precision == EAGLE_PREC_F16) {                      // the fp16 kernels address tensors through raw buffer descriptors with 32-bit byte offsets
         const size_t lim = (size_t)1 << 31;
@@ -1160,12 +975,6 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     ensure_max_dynamic_lds((const void*)inst->fn, 160 * 1024);
     const int gy = c.cout_pad / (c.nt * 16);
     int gx = a.tiles_x * a.tiles_y * a.N;
-    const bool dma = c.variant == 1 || c.variant == 5;
-    if (dma) {                                              // persistent: as many workgroups as stay resident, 1-D over items
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-        gx = std::min(gx * gy, 256 * per_cu);
-        a.zeros = conv_zero_page();
-    }
     if (conv_ws(c)) {                                       // persistent, weight-stationary: 8*gy | grid, as many workgroups as stay resident
         if (c.kc != c.cin || a.out_f32 || a.r2 || a.pre_act != 0 || a.post_act > 1 || (size_t)a.N * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.N * a.Ho * a.Wo * std::max(a.ycs, a.r1 ? a.r1cs : 0) * 2 >= (1ull << 31))
             fail(EAGLE_E_NOKERNEL, "weight-stationary conv needs kc == cin, fp16 output, at most one residual, pre_act none, post_act in {none, ReLU} and tensors below 2 GiB (kc=%d cin=%d)", c.kc, c.cin);
@@ -1177,10 +986,10 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     static const int xcd_env = getenv("EAGLE_CONV_XCD") ? atoi(getenv("EAGLE_CONV_XCD")) : 1;
     // 1x1 layers with several Cout blocks re-read their input tile once per block: in tile-major / block-minor order on one XCD the
     // re-reads hit that XCD's L2 instead of HBM
-    a.xcd = (precision == EAGLE_PREC_F16 && c.variant != 1 && c.variant != 5 && !conv_ws(c) && (c.ks == 3 || (c.ks == 1 && gy > 1)) && xcd_env) ? 1 : 0;
+    a.xcd = (precision == EAGLE_PREC_F16 && !conv_ws(c) && (c.ks == 3 || (c.ks == 1 && gy > 1)) && xcd_env) ? 1 : 0;
     dim3 grid(gx, gy);
     if (a.xcd) grid = dim3(gx * gy, 1);
-    if (dma || conv_ws(c)) grid = dim3(gx, 1);
+    if (conv_ws(c)) grid = dim3(gx, 1);
     hipLaunchKernelGGL(inst->fn, grid, dim3(256), lds, s, a);
     HIP_CHECK(hipGetLastError());
 }

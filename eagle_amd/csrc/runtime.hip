@@ -108,6 +108,7 @@ struct Op {
 
 struct Net {                      // one launch schedule + the device memory it owns
     std::vector<Op> ops;
+    std::vector<std::unique_ptr<std::string>> names;   // layer-shape labels of the convolutions (Op::tag points into them)
     std::vector<void*> owned;
     std::multimap<size_t, void*> free_list[4];   // one pool per stream: a buffer is recycled only by work ordered after its last use
     int pool = 0;                                // pool of the stream the builder is currently emitting for
@@ -183,6 +184,7 @@ struct EagleHandle {
     std::vector<hipEvent_t> span_pool; size_t span_used = 0;
     std::vector<Span> spans;                     // non-convolution launches of the step being profiled
     std::vector<EagleKernelTime> ktab;           // accumulated per kernel name since eagle_set_profiling(1)
+    std::vector<const Op*> conv_ops;             // the convolution behind each conv_ev pair of the step being profiled
     EagleTimings timings{};
     double conv_flop_step = 0; int n_conv = 0, n_launch = 0;
     // clip session of the optical-flow cadence (eagle_clip_*)
@@ -292,7 +294,15 @@ struct Builder {
         if (am_slot) { H->hm_chunks = conv_tiles_per_frame(L.cfg, ho, wo); H->fused_argmax = true; }
         L.flop = 2.0 * N * ho * wo * (double)cout * cin * ks * ks;
         const int pr = prec;
-        Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = "conv"; op.stream = cur_stream;
+        char label[64];
+        snprintf(label, sizeof(label), "conv %dx%d/%d %d->%d @%dx%d", ks, ks, stride, cin, cout, ho, wo);
+        net->names.emplace_back(new std::string(label));
+        Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = net->names.back()->c_str(); op.stream = cur_stream;
+        {   // algorithmic HBM bytes of the launch: input once, output once, each residual once, weights once
+            const double es = prec == EAGLE_PREC_F16 ? 2 : 4;
+            op.bytes = (double)N * x.h * x.w * cin * es + (double)N * ho * wo * cout * ((out_f32 || prec == EAGLE_PREC_F32) ? 4 : 2) * (am_slot ? 0 : 1) +
+                       (r1 ? (double)N * ho * wo * cout * es : 0) + (r2 ? (double)N * ho * wo * cout * es : 0) + (double)ks * ks * cin * cout * es;
+        }
         op.run = [L, pr](hipStream_t s) { conv_launch(pr, L, s); };
         net->ops.push_back(op);
         return L.y;
@@ -581,6 +591,7 @@ static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
             HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], st));
             op.run(st);
             HIP_CHECK(hipEventRecord(h->conv_ev[ev_i++], st));
+            h->conv_ops.push_back(&op);
         } else {
             timed(h, op.tag, op.bytes, st, [&] { op.run(st); });
         }
@@ -665,7 +676,13 @@ static void collect_step(EagleHandle* h, int p, int n_active, EagleFrameResult* 
             float t = 0.f;
             HIP_CHECK(hipEventElapsedTime(&t, h->conv_ev[i], h->conv_ev[i + 1]));
             h->timings.conv_ms += t;
+            if (i / 2 < h->conv_ops.size()) {
+                const Op* op = h->conv_ops[i / 2];
+                EagleKernelTime& e = h->ktab[ktab_index(h, op->tag)];
+                e.ms += t; e.launches += 1; e.bytes += op->bytes; e.flop += op->flop;
+            }
         }
+        h->conv_ops.clear();
         for (const EagleHandle::Span& sp : h->spans) {
             float t = 0.f;
             HIP_CHECK(hipEventElapsedTime(&t, sp.a, sp.b));

@@ -39,7 +39,7 @@ class EagleTrackParams(C.Structure):
 
 
 class EagleKernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("ms", C.c_float), ("launches", C.c_int32), ("bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 40), ("ms", C.c_float), ("launches", C.c_int32), ("bytes", C.c_double), ("flop", C.c_double)]
 
 
 # numpy mirrors of the record structs (C layout, natural alignment — checked against sizeof in tests)
@@ -321,10 +321,11 @@ class Handle:
         return t
 
     def kernel_times(self):
-        """[(name, total ms, launches, algorithmic bytes)] of the non-convolution launches since set_profiling(1)."""
-        buf = (EagleKernelTime * 32)(); n = C.c_int(0)
-        self._check(self.L.eagle_get_kernel_times(self._h, buf, 32, C.byref(n)), "get_kernel_times")
-        return [(buf[i].name.decode(), float(buf[i].ms), int(buf[i].launches), float(buf[i].bytes)) for i in range(min(n.value, 32))]
+        """[(name, total ms, launches, algorithmic bytes, flop)] since set_profiling(1): one row per non-convolution kernel and one per
+        convolution layer shape ("conv 3x3/1 96->96 @68x120")."""
+        buf = (EagleKernelTime * 256)(); n = C.c_int(0)
+        self._check(self.L.eagle_get_kernel_times(self._h, buf, 256, C.byref(n)), "get_kernel_times")
+        return [(buf[i].name.decode(), float(buf[i].ms), int(buf[i].launches), float(buf[i].bytes), float(buf[i].flop)) for i in range(min(n.value, 256))]
 
     # --- multi-GPU -------------------------------------------------------------------------------------
     def comm_init(self, rank, world, uid_bytes):

@@ -210,7 +210,7 @@ int eagle_get_timings(EagleHandle* h, EagleTimings* t);
 /* Profiling mode also times every non-convolution launch (HIP events on its launch stream) and accumulates, per kernel name, the
  * elapsed time and the ALGORITHMIC HBM bytes of the launches (inputs read once + outputs written once): the HBM-roofline
  * rows of bench.py.  The table is cleared by eagle_set_profiling(h, 1). */
-typedef struct EagleKernelTime { char name[32]; float ms; int32_t launches; double bytes; } EagleKernelTime;
+typedef struct EagleKernelTime { char name[40]; float ms; int32_t launches; double bytes; double flop; } EagleKernelTime;   /* convolutions: one row per layer shape, flop = 2*MAC */
 int eagle_get_kernel_times(EagleHandle* h, EagleKernelTime* out, int cap, int* n);
 
 /* Operator-level entry points (host buffers in/out) used by the parity tests: each runs ONE kernel of the path.

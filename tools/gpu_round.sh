@@ -3,12 +3,12 @@
 tag=${1:-x}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log | tail -1
-python bench.py --cadence 25 > $O/bench.json 2> $O/bench.err; cat $O/bench.json
+timeout 2400 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log | tail -1
+timeout 1200 python bench.py --cadence 25 --host-frames > $O/bench.json 2> $O/bench.err; cat $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --cadence 25 > $O/prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extras --cadence 25 > $O/prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1
 cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/conv_hbm_traffic.json --steps 2 --warmup 0 --no-cpu-baseline
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete
 ls -R $O | head -30

@@ -1,7 +1,7 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md §HBM prescribes) of the
 bench command into HBM bytes per convolution launch.  Corrections per the guide: counters are in KiB
 (bytes = value * 1024) and on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read stream (x2)."""
-import csv, glob, json, sys
+import csv, glob, hashlib, json, os, sys
 
 def load(d, counter):
     f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))[0]
@@ -16,7 +16,8 @@ def load(d, counter):
     return per
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {"batch": 50, "detector": "n", "precision": "f16", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + " ".join(sys.argv[4:]),
+_lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "eagle_amd", "libeagle_hip.so")
+out = {"build": "libeagle_hip.so md5 " + hashlib.md5(open(_lib, "rb").read()).hexdigest()[:12] if os.path.exists(_lib) else "?", "batch": 50, "detector": "n", "precision": "f16", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + " ".join(sys.argv[4:]),
        "corrections": "bytes = KiB*1024; FETCH_SIZE doubled (gfx950 under-report of wide coalesced reads)", "kernels": {}}
 tf = tw = n = 0
 for k in fetch:

@@ -654,6 +654,206 @@ __global__ __launch_bounds__(256, WGS) void conv_f16_ws_kernel(ConvArgs a)
 
 
 // ------------------------------------------------------------------------------------------------------------
+// fp16 family, variants 8 / 9: "A-direct" 3x3 stride-1 kernel for Cout a multiple of 96 (HRNet's 96 / 192 / 384-channel branches).
+//   * four waves = PG pixel groups x CQ Cout groups; a wave owns 4 rows x 32 pixels (8 sub-tiles) x 48 output channels: 24 MFMAs per
+//     K-step of 32 from 3 weight and 8 activation fragments;
+//   * WEIGHT fragments never touch LDS: the weight image is fragment-major (16 bytes per lane), so the three A fragments of a K-step are
+//     three coalesced buffer_load_dwordx4 straight into registers, requested two K-steps ahead (ring of three, static slots);
+//   * ACTIVATIONS: the halo tile of a 32-channel chunk by LDS-DMA into a two-deep ring that runs continuously over the workgroup's
+//     items (XCD-contiguous ranges), one s_barrier per chunk (9 K-steps = 216 MFMAs per wave).  Pixel stride 96 B (4 channel groups + 2
+//     pad slots) makes the ds_read_b128 of a B fragment conflict-free with ONE address register and immediates;
+//   * every wave requests the same number of LDS-DMA slabs, so all waits are static vmcnt counts; out-of-image pixels and stores use the
+//     descriptor's range check (offset 2^31), no divergent branches;
+//   * epilogue wave-private (own LDS strip, no barrier): residual fetched as coalesced 16-byte pieces for all rows at once, through the
+//     strip into the MFMA layout, results back through the strip as 16-byte stores.  Two workgroups per CU: one's epilogue runs
+//     under the other's MFMAs.
+// Measured (tools/convbench/ad_main.hip, B = 50): 96->96@68x120 83 us (tuned generic kernel 94), 192->192@34x60 70 us (85),
+// 384->384@17x30 67 us (100).
+// ------------------------------------------------------------------------------------------------------------
+template <int CQ, int PG>
+__global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
+{
+    static_assert(CQ * PG == 4, "four waves per workgroup");
+    using rsrc_t = __amdgpu_buffer_rsrc_t;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NT = 3, PW = 8, NW = 4, BN = CQ * 48, TH = 4 * PG;
+    constexpr int KSTEP = 4 * BN * 16;                   // bytes of one K-step (32 input channels of one tap) of the weight image
+    constexpr int HW_ = 34, HPIX = (TH + 2) * HW_, PS = 96;
+    constexpr int HSLABS = ((HPIX * PS + 1023) / 1024 + NW - 1) / NW * NW, HB = HSLABS * 1024, HK = HSLABS / NW;
+    constexpr int RS = 48 * 2 + 16, STRIP = 32 * RS;     // one output row of the wave (32 pixels x 48 channels) per pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Hb = smem;                                // 2 x HB
+    char* const strip = smem + 2 * HB + (threadIdx.x >> 6) * STRIP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cq = wave % CQ, pg = wave / CQ, q = lane >> 4, lx = lane & 15;
+    const int gy = a.gy, nitems = a.tiles_x * a.tiles_y * a.N * gy, nwg = gridDim.x;
+    int item0, item_end;
+    {
+        const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
+        const int wgs_here = (nwg + 7 - xcd) >> 3;
+        const int qn = nitems >> 3, rn = nitems & 7;
+        const int x0 = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+        const int xc = qn + (xcd < rn ? 1 : 0);
+        item0 = x0 + (int)((long)xc * k / wgs_here);
+        item_end = x0 + (int)((long)xc * (k + 1) / wgs_here);
+    }
+    if (item0 >= item_end) return;
+    const int nloc = item_end - item0, nch = a.nchunks, GC = nloc * nch;
+    const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7FFFFFFF, 0x00020000);
+    const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7FFFFFFF, 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.r1, 0, 0x7FFFFFFF, 0x00020000);
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7FFFFFFF, 0x00020000);
+    int hpk[HK];                                          // per slab: halo row | column << 8 | channel slot << 16, or -1 (padding)
+#pragma unroll
+    for (int k = 0; k < HK; ++k) {
+        const int e = (wave + NW * k) * 64 + lane;
+        const int pix = e / 6, slot = e - pix * 6;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        hpk[k] = (pix < HPIX && slot < 4) ? (hy | (hx << 8) | (slot << 16)) : -1;
+    }
+    const int bbase = ((pg * 4) * HW_ + lx) * PS + q * 16;      // B fragments: one address register, everything else is an immediate
+    const unsigned wlane = (unsigned)((q * BN + cq * 48 + lx) * 16);
+
+    auto decode = [&](int item, int& n, int& ty, int& tx, int& nb) {
+        int t = item / gy; nb = item - t * gy;
+        tx = t % a.tiles_x; t /= a.tiles_x;
+        ty = t % a.tiles_y; n = t / a.tiles_y;
+    };
+    // ---- halo ring: global chunk index = local item * nch + chunk; slot = index & 1 -------------------------------------------
+    int h_g = 0, h_ch = 0, h_item = item0;
+    int h_iy0, h_ix0, h_gb;                                // geometry of the item the next request belongs to (scalars)
+    auto halo_origin = [&](int item) {
+        int n, ty, tx, nb; decode(item, n, ty, tx, nb);
+        h_iy0 = ty * TH - 1; h_ix0 = tx * 32 - 1;
+        h_gb = (((n * a.H + h_iy0) * a.W + h_ix0) * a.xcs + a.xoff) * 2;
+    };
+    halo_origin(h_item);
+    auto issue_h = [&]() {
+        char* dst = Hb + (h_g & 1) * HB;                  // (past the last chunk: the same requests again, harmlessly, so that the count stays static)
+        const unsigned so = (unsigned)(h_ch * 32) * 2u;
+#pragma unroll
+        for (int k = 0; k < HK; ++k) {
+            const int hy = hpk[k] & 0xFF, hx = (hpk[k] >> 8) & 0xFF, slot = (hpk[k] >> 16) & 7;
+            const int iy = h_iy0 + hy, ix = h_ix0 + hx;
+            const unsigned off = (hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                                     ? (unsigned)(h_gb + ((hy * a.W + hx) * a.xcs + slot * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + (wave + NW * k) * 1024), 16, off, so, 0, 0);
+        }
+        if (h_g + 1 >= GC) return;
+        ++h_g;
+        if (++h_ch == nch) { h_ch = 0; ++h_item; halo_origin(h_item); }
+    };
+    issue_h();
+    int gc = 0;
+    for (int item = item0; item < item_end; ++item) {
+        int n, ty, tx, nb; decode(item, n, ty, tx, nb);
+        const int oy0 = ty * TH, ox0 = tx * 32;
+        f32x4 acc[NT][PW];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int p = 0; p < PW; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A ring: fragments of K-steps kk, kk + 1, kk + 2 (slot = kk % 3; nine K-steps per chunk keep the slots static)
+        u32x4 A[3][NT];
+        unsigned wsrc = (unsigned)(nb * nch * 36) * (unsigned)(BN * 16);     // K-step 0 of this item
+        const unsigned wend = wsrc + (unsigned)(nch * 9) * KSTEP;
+        auto load_a = [&](int slot) {                      // requests the next K-step of the item (the last two requests of an item repeat its last K-step)
+            const unsigned so = wsrc < wend ? wsrc : wend - KSTEP;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) A[slot][tt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane + tt * 256, so, 0);
+            wsrc += KSTEP;
+        };
+        load_a(0); load_a(1);
+        for (int ch = 0; ch < nch; ++ch, ++gc) {
+            // chunk gc has landed (requested one chunk ago); every wave is done with the other slot
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // everything older than the two K-steps of A in flight
+            __builtin_amdgcn_s_barrier();
+            issue_h();                                              // chunk gc + 1 into the slot chunk gc - 1 used
+            const char* hb = Hb + (gc & 1) * HB + bbase;
+            half8 B[2][PW];
+            auto read_b = [&](int slot, int kk) {
+                const int ky = kk / 3, kx = kk - ky * 3;
+#pragma unroll
+                for (int p = 0; p < PW; ++p)
+                    B[slot][p] = *(const half8*)(hb + (((p >> 1) + ky) * HW_ + (p & 1) * 16 + kx) * PS);
+            };
+            read_b(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) {
+                load_a((kk + 2) % 3);
+                if (kk + 1 < 9) read_b((kk + 1) & 1, kk + 1);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int p = 0; p < PW; ++p)
+                        acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16((half8)A[kk % 3][tt], B[kk & 1][p], acc[tt][p], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int co0 = nb * BN + cq * 48;
+        __builtin_amdgcn_sched_barrier(0);
+        float4 bias[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) bias[tt] = *(const float4*)(a.bias + co0 + tt * 16 + q * 4);
+        // piece e = i * 64 + lane of a row: pixel e / 6, 16-byte group e % 6
+        int pstrip[3];
+        u32x4 rres[4][3];
+        if (a.r1) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int e = i * 64 + lane, px = e / 6, gq = e - px * 6, ox2 = ox0 + px;
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2) {
+                    const int oy = oy0 + pg * 4 + r2;
+                    const unsigned off = (oy < a.Ho && ox2 < a.Wo) ? (unsigned)((((n * a.Ho + oy) * a.Wo + ox2) * a.r1cs + a.r1off + co0 + gq * 8) * 2) : OOB;
+                    rres[r2][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, 0);
+                }
+            }
+        }
+        unsigned poff[4][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = i * 64 + lane, px = e / 6, gq = e - px * 6, ox2 = ox0 + px;
+            pstrip[i] = px * RS + gq * 16;
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2) {
+                const int oy = oy0 + pg * 4 + r2;
+                poff[r2][i] = (oy < a.Ho && ox2 < a.Wo) ? (unsigned)((((n * a.Ho + oy) * a.Wo + ox2) * a.ycs + a.yoff + co0 + gq * 8) * 2) : OOB;
+            }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+            if (a.r1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *(u32x4*)(strip + pstrip[i]) = rres[r2][i];
+            }
+#pragma unroll
+            for (int xb2 = 0; xb2 < 2; ++xb2) {
+                const int p = r2 * 2 + xb2;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    char* sp = strip + (xb2 * 16 + lx) * RS + (tt * 16 + q * 4) * 2;
+                    float v[4] = {acc[tt][p][0] + bias[tt].x, acc[tt][p][1] + bias[tt].y, acc[tt][p][2] + bias[tt].z, acc[tt][p][3] + bias[tt].w};
+                    if (a.r1) {
+                        const half4 rv = *(const half4*)sp;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
+                    }
+                    if (a.post_act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                    }
+                    half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *(half4*)sp = o;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, poff[r2][i], 0, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // fp32 exact family.  KC = 16 (or 4 for the 3-channel stems); canonical K order.
 // ------------------------------------------------------------------------------------------------------------
 template <int KS, int S, int KC, int NT>
@@ -770,12 +970,17 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
+static bool conv_ad(const ConvConfig& c) { return c.variant == 8 || c.variant == 9; }      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96)
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     const int hw = (tw - 1) * c.stride + c.ks, hh = (th - 1) * c.stride + c.ks;
     const int bn = c.nt * 16;
+    if (precision == EAGLE_PREC_F16 && conv_ad(c)) {
+        const int pgn = c.variant == 8 ? 1 : 2, slabs = (((4 * pgn + 2) * 34 * 96 + 1023) / 1024 + 3) / 4 * 4;
+        return (size_t)2 * slabs * 1024 + 4 * 32 * 112;
+    }
     if (precision == EAGLE_PREC_F16) {
         const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)hh * hw * f16_ps(c.kc);
         const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 2 + 16);        // output transpose, one strip per wave
@@ -787,6 +992,7 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
 size_t conv_lds_bytes(int precision, const ConvConfig& c) { return lds_bytes(precision, c); }
 int conv_tiles_per_frame(const ConvConfig& c, int ho, int wo)
 {
+    if (conv_ad(c)) return ((wo + 31) / 32) * ((ho + (c.variant == 8 ? 4 : 8) - 1) / (c.variant == 8 ? 4 : 8));
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     return ((wo + tw - 1) / tw) * ((ho + th - 1) / th);
 }
@@ -823,6 +1029,8 @@ static const Inst g_inst[] = {
     {EAGLE_PREC_F16, 3, 1, 64, 4, 6, conv_f16_ws_kernel<64, 4, 4, 1>}, {EAGLE_PREC_F16, 3, 1, 64, 4, 7, conv_f16_ws_kernel<64, 4, 2, 1>},
     {EAGLE_PREC_F16, 3, 1, 96, 3, 6, conv_f16_ws_kernel<96, 3, 4, 1>}, {EAGLE_PREC_F16, 3, 1, 96, 3, 7, conv_f16_ws_kernel<96, 3, 2, 1>},
     {EAGLE_PREC_F16, 3, 1, 96, 2, 7, conv_f16_ws_kernel<96, 2, 2, 1>},
+    // A-direct 3x3 stride-1 kernels (variant 8: BN = 192, tile 4 x 32; variant 9: BN = 96, tile 8 x 32); kc = 32
+    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, conv_f16_ad_kernel<4, 1>}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, conv_f16_ad_kernel<2, 2>},
     // exact fp32 family
     ALLNT32(3, 1, 16), ALLNT32(3, 2, 16), ALLNT32(3, 2, 4), ALLNT32(1, 1, 16),
 };
@@ -857,8 +1065,15 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
     if (const char* f = getenv("EAGLE_CONV_FORCE")) {
         ConvConfig q = c;
         if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 &&
-            find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024 && (!conv_ws(q) || plain_epilogue))
+            find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024 && ((!conv_ws(q) && !conv_ad(q)) || plain_epilogue))
             return q;
+    }
+    // 3x3 stride-1 layers whose Cout is a multiple of 96 (HRNet's 96 / 192 / 384-channel branches): the A-direct kernel (EAGLE_CONV_AD=0: off)
+    static const bool ad_on = !(getenv("EAGLE_CONV_AD") && atoi(getenv("EAGLE_CONV_AD")) == 0);
+    if (ad_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 32 == 0 && cout_pad % 96 == 0) {
+        ConvConfig q = c; q.kc = 32;
+        if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 8; } else { q.nt = 6; q.variant = 9; }
+        return q;
     }
     // fp16: per-layer table measured on MI355X (tools/autotune_conv.py); shapes not in the table use the heuristic below
     for (const Tuned& t : g_tuned)
@@ -963,6 +1178,21 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.nchunks = c.cin / c.kc;
     a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
+    if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
+        if (a.out_f32 || a.r2 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != 32 || c.ks != 3 || c.stride != 1)
+            fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3 stride 1, kc = 32, fp16 output, at most one residual, pre_act none, post_act in {none, ReLU}");
+        const int thh = c.variant == 8 ? 4 : 8;
+        a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + thh - 1) / thh;
+        a.gy = c.cout_pad / (c.nt * 16);
+        const size_t lim = (size_t)1 << 31;
+        if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(a.ycs, a.r1 ? a.r1cs : 0) * 2 >= lim)
+            fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
+        ensure_max_dynamic_lds((const void*)inst->fn, 160 * 1024);
+        const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
+        hipLaunchKernelGGL(inst->fn, dim3(std::min(items, 512)), dim3(256), lds_bytes(precision, c), s, a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (a.am && (precision != EAGLE_PREC_F16 || conv_ws(c)))
         fail(EAGLE_E_NOKERNEL, "fused heat-map maxima need the generic fp16 kernel");
     if (precision == EAGLE_PREC_F16) {                      // the fp16 kernels address tensors through raw buffer descriptors with 32-bit byte offsets

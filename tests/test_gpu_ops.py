@@ -76,6 +76,29 @@ def test_conv_weight_stationary_variants(force, cin, cout, shape, monkeypatch):
     assert err < F16_TOL, f"fp16 weight-stationary conv error {err}"
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 96), (192, 192), (64, 192), (384, 384), (32, 96)])
+@pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (5, 17, 30), (1, 68, 120)])
+@pytest.mark.parametrize("res,post", [(True, 1), (False, 1), (False, 0)])
+def test_conv_a_direct_variants(cin, cout, shape, res, post):
+    """The A-direct 3x3 stride-1 kernels (conv.hip variants 8 / 9: weight fragments straight from global memory, activations by
+    LDS-DMA), which conv_choose picks for Cout = 96 / 192 / 384, against the oracle: ragged maps (partial tiles in both directions,
+    fewer items than workgroups, several items per workgroup and Cout blocks), with / without residual and ReLU."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    if shape[1] * shape[2] > 4000 and (cin > 96 or not res):
+        pytest.skip("large map: one representative case")
+    n, h, w = shape
+    x = _rand((n, h, w, cin), 21)
+    wt = _rand((3, 3, cin, cout), 22, (2.0 / (cin * 9)) ** 0.5)
+    b = _rand((cout,), 23, 0.1)
+    r1 = _rand((n, h, w, cout), 24) if res else None
+    q = P.round_f16
+    ref = P.conv2d(q(x), q(wt), b, stride=1, pre=0, r1=q(r1) if res else None, r2=None, post=post, f16_out=True)
+    got = lib.op_conv2d(x, wt, b, 1, 0, r1, None, post, lib.PREC_F16)
+    err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < F16_TOL, f"fp16 A-direct conv error {err}"
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16"])
 def test_fuse_sum_parity(prec):
     from eagle_amd import lib

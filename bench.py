@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the network phase as a hipGraph (no gain once a step is GPU-bound)")
     ap.add_argument("--host-frames", action="store_true", help="(kept for compatibility: the PCIe-inclusive path is always timed at N = 1)")
+    ap.add_argument("--all-layers", action="store_true", help="roofline_conv_layers lists every convolution layer shape instead of the ten heaviest")
     ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / exact_family / roofline_hbm (profiling runs)")
     ap.add_argument("--exact-frames", type=int, default=100, help="frames of the fp32 exact-family run")
     ap.add_argument("--cadence", type=int, default=0, metavar="FPS", help="also time the reference's default cadence on the same clip: get_coordinates(frames, FPS, num_homography=1, "
@@ -288,7 +289,7 @@ def main():
         if hbm_rows:
             res["roofline_hbm"] = hbm_rows
         if conv_rows:      # the ten convolution layer shapes that take the most time, each against BOTH roofs (MFMA peak; 6.3 TB/s achievable HBM)
-            res["roofline_conv_layers"] = sorted(conv_rows, key=lambda r: -r["ms_per_step"])[:10]
+            res["roofline_conv_layers"] = sorted(conv_rows, key=lambda r: -r["ms_per_step"])[:(len(conv_rows) if a.all_layers else 10)]
         if exact is not None:
             res["exact_family"] = exact
         if cadence is not None:

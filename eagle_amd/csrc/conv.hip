@@ -1189,7 +1189,8 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         ensure_max_dynamic_lds((const void*)inst->fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
-        hipLaunchKernelGGL(inst->fn, dim3(std::min(items, 512)), dim3(256), lds_bytes(precision, c), s, a);
+        static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)
+        hipLaunchKernelGGL(inst->fn, dim3(std::min(items, slots)), dim3(256), lds_bytes(precision, c), s, a);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -1208,7 +1209,8 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     if (conv_ws(c)) {                                       // persistent, weight-stationary: 8*gy | grid, as many workgroups as stay resident
         if (c.kc != c.cin || a.out_f32 || a.r2 || a.pre_act != 0 || a.post_act > 1 || (size_t)a.N * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.N * a.Ho * a.Wo * std::max(a.ycs, a.r1 ? a.r1cs : 0) * 2 >= (1ull << 31))
             fail(EAGLE_E_NOKERNEL, "weight-stationary conv needs kc == cin, fp16 output, at most one residual, pre_act none, post_act in {none, ReLU} and tensors below 2 GiB (kc=%d cin=%d)", c.kc, c.cin);
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+        static const int ws_cap = getenv("EAGLE_CONV_WS_PER_CU") ? atoi(getenv("EAGLE_CONV_WS_PER_CU")) : 2;     // developer knob, as above
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(ws_cap, (160 * 1024) / lds));
         const int unit = 8 * gy;
         gx = std::max(unit, std::min((gx * gy + unit - 1) / unit * unit, 256 * per_cu / unit * unit));
     }

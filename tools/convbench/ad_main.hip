@@ -30,7 +30,7 @@ struct G8Args {
 
 
 // CQ = 4: tile 8 x 32 pixels x 192 channels (waves: 2 pixel halves x 4 Cout quarters); CQ = 2: tile 16 x 32 x 96 (4 x 2)
-template <int CQ, int PG>
+template <int CQ, int PG, bool RES = true>
 __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_kernel(G8Args a)
 {
 #if __HIP_DEVICE_COMPILE__        // (the host pass of this hipcc drops the stub of this template when it sees the body; tool file only)
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_ke
     };
     issue_h();
 #ifdef TIMING
-    long long t_wait = 0, t_main = 0, t_epi = 0; long long tprev = __builtin_readcyclecounter(); const long long t_k0 = tprev;
+    long long t_wait = 0, t_main = 0, t_epi = 0, t_eld = 0; const long long rt0 = __builtin_amdgcn_s_memrealtime(); long long tprev = __builtin_readcyclecounter(); const long long t_k0 = tprev;
 #define TS(var_) { const long long now_ = __builtin_readcyclecounter(); var_ += now_ - tprev; tprev = now_; }
 #else
 #define TS(var_)
@@ -144,6 +144,23 @@ __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_ke
             read_b(0, 0);
 #pragma unroll
             for (int kk = 0; kk < 9; ++kk) {
+#ifndef RPRE
+#define RPRE 1
+#endif
+                if (RPRE && kk >= 7 && ch == nch - 1 && RES) {
+                    // the item's last two K-steps have no weights left to request: their ring slots take the residual pieces of output rows
+                    // 0 and 1 instead (same number of requests on both paths, so every vmcnt stays static)
+                    const int r2 = kk - 7, oy = oy0 + pg * 4 + r2;
+                    int lane_ = lane;
+                    asm volatile("" : "+v"(lane_));        // keeps the piece geometry out of the loop-invariant registers
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int e = i * 64 + lane_, px = e / 6, gq = e - px * 6, ox2 = ox0 + px;
+                        const unsigned off = (oy < a.H && ox2 < a.W) ? (unsigned)((((n * a.H + oy) * a.W + ox2) * a.CO + nb * BN + cq * 48 + gq * 8) * 2) : OOB_OFF;
+                        A[(kk + 2) % 3][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, 0);
+                    }
+                    wsrc += KSTEP;
+                } else
                 load_a((kk + 2) % 3);
                 if (kk + 1 < 9) read_b((kk + 1) & 1, kk + 1);
 #pragma unroll
@@ -164,31 +181,62 @@ __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_ke
         for (int tt = 0; tt < NT; ++tt) bias[tt] = *(const float4*)(a.bias + co0 + tt * 16 + q * 4);
         // piece e = i * 64 + lane of a row: pixel e / 6, 16-byte group e % 6; out-of-image pieces get the out-of-range offset (loads return
         // zeros, stores are dropped): no divergent branches
-        unsigned poff[4][3];
-        int pstrip[3];
+        // piece e = i * 64 + lane of a row: pixel e / 6, 16-byte group e % 6; out-of-image pieces get the out-of-range offset (loads return
+        // zeros, stores are dropped): no divergent branches.  Offsets are recomputed where they are used (registers are scarce here).
+        int pstrip[3], ppx[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int e = i * 64 + lane, px = e / 6, gq = e - px * 6, ox2 = ox0 + px;
+            const int e = i * 64 + lane, px = e / 6, gq = e - px * 6;
             pstrip[i] = px * RS + gq * 16;
-#pragma unroll
-            for (int r2 = 0; r2 < 4; ++r2) {
-                const int oy = oy0 + pg * 4 + r2;
-                poff[r2][i] = (oy < a.H && ox2 < a.W) ? (unsigned)((((n * a.H + oy) * a.W + ox2) * a.CO + co0 + gq * 8) * 2) : OOB_OFF;
-            }
+            ppx[i] = px | (gq << 8);
         }
+        auto piece_off = [&](int r2, int i) -> unsigned {
+            const int oy = oy0 + pg * 4 + r2, ox2 = ox0 + (ppx[i] & 0xFF), gq = ppx[i] >> 8;
+            return (oy < a.H && ox2 < a.W) ? (unsigned)((((n * a.H + oy) * a.W + ox2) * a.CO + co0 + gq * 8) * 2) : OOB_OFF;
+        };
+#ifndef EPI
+#define EPI 0
+#endif
+#if EPI == 0
         u32x4 rres[4][3];
-        if (a.r1) {
+        if (RES) {
 #pragma unroll
             for (int r2 = 0; r2 < 4; ++r2)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) rres[r2][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, poff[r2][i], 0, 0);
+                for (int i = 0; i < 3; ++i) rres[r2][i] = (RPRE && r2 < 2) ? A[r2][i] : __builtin_amdgcn_raw_buffer_load_b128(rrs, piece_off(r2, i), 0, 0);
         }
+#else
+        // residual straight in the MFMA layout: 8 bytes per lane (a pixel's 96 bytes are completed by this wave's 12 requests)
+        u32x2 rres[4][2][NT];
+        unsigned qoff[4][2];
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+            for (int xb2 = 0; xb2 < 2; ++xb2) {
+                const int oy = oy0 + pg * 4 + r2, ox = ox0 + xb2 * 16 + lx;
+                qoff[r2][xb2] = (oy < a.H && ox < a.W) ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.CO + co0 + q * 4) * 2) : OOB_OFF;
+            }
+        if (RES) {
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+                for (int xb2 = 0; xb2 < 2; ++xb2)
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) rres[r2][xb2][tt] = __builtin_amdgcn_raw_buffer_load_b64(rrs, qoff[r2][xb2] + tt * 32, 0, 0);
+        }
+#endif
+#if defined(TIMING) && TIMING == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TS(t_eld)
+#endif
 #pragma unroll
         for (int r2 = 0; r2 < 4; ++r2) {
-            if (a.r1) {
+#if EPI == 0
+            if (RES) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) *(u32x4*)(strip + pstrip[i]) = rres[r2][i];
             }
+#endif
 #pragma unroll
             for (int xb2 = 0; xb2 < 2; ++xb2) {
                 const int p = r2 * 2 + xb2;
@@ -196,8 +244,12 @@ __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_ke
                 for (int tt = 0; tt < NT; ++tt) {
                     char* sp = strip + (xb2 * 16 + lx) * RS + (tt * 16 + q * 4) * 2;
                     float v[4] = {acc[tt][p][0] + bias[tt].x, acc[tt][p][1] + bias[tt].y, acc[tt][p][2] + bias[tt].z, acc[tt][p][3] + bias[tt].w};
-                    if (a.r1) {
+                    if (RES) {
+#if EPI == 0
                         const half4 rv = *(const half4*)sp;
+#else
+                        const half4 rv = (half4)rres[r2][xb2][tt];
+#endif
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
                     }
@@ -206,19 +258,25 @@ __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_ke
                         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
                     }
                     half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+#if EPI == 2
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2)o, yrs, qoff[r2][xb2] + tt * 32, 0, 0);
+#else
                     *(half4*)sp = o;
+#endif
                 }
             }
+#if EPI != 2
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, poff[r2][i], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, piece_off(r2, i), 0, 0);
+#endif
         }
         TS(t_epi)
     }
 #ifdef TIMING
     if (blockIdx.x == 17 && lane == 0) {
         long long* d = (long long*)a.dbg + wave * 8;
-        d[0] = t_wait; d[1] = t_main; d[2] = t_epi; d[4] = __builtin_readcyclecounter() - t_k0; d[5] = GC;
+        d[0] = t_wait; d[1] = t_main; d[2] = t_epi; d[3] = t_eld; d[4] = __builtin_readcyclecounter() - t_k0; d[5] = GC; d[6] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
 #endif
 #endif
@@ -296,7 +354,7 @@ static void run(const Shape& sh)
     }
 #ifdef TIMING
     { long long d[64]; hipMemcpy(d, a.dbg, sizeof(d), hipMemcpyDeviceToHost);
-      for (int w = 0; w < 1; ++w) printf("   wave %d: %lld ticks over %lld chunks: waits %lld, barrier+main %lld, epilogues %lld\n", w, d[w*8+4], d[w*8+5], d[w*8+0], d[w*8+1], d[w*8+2]); }
+      for (int w = 0; w < 1; ++w) printf("   wave %d: %lld ticks (%.0f MHz) over %lld chunks: waits %lld, barrier+main %lld, epilogues %lld + their loads %lld\n", w, d[w*8+4], d[w*8+4] / (d[w*8+6] / 100.0), d[w*8+5], d[w*8+0], d[w*8+1], d[w*8+2], d[w*8+3]); }
 #endif
     const double fl = 2.0 * sh.n * sh.h * sh.w * (double)cout * cin * 9;
     printf("%-20s ad CQ=%d PG=%d BN=%d wgs/cu=%d items=%d  %8.1f us  %7.1f TFLOP/s   NaN %d  max rel err %.2e\n", sh.name, CQ, PG, BN, wgs_per_cu, items,

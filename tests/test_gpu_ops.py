@@ -100,15 +100,20 @@ def test_conv_a_direct_variants(cin, cout, shape, res, post):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16"])
-def test_fuse_sum_parity(prec):
+@pytest.mark.parametrize("shape,upshapes", [((2, 27, 31, 48), [(14, 16), (7, 8), (4, 4)]), ((1, 135, 240, 48), [(68, 120), (34, 60), (17, 30)]),
+                                            ((3, 34, 60, 192), [(17, 30)]), ((2, 9, 33, 96), [(5, 17), (1, 1)])])
+def test_fuse_sum_parity(prec, shape, upshapes):
+    """K4 against the oracle, bit for bit in both families (the fp16 family runs the LDS-tiled form: full and partial 8 x 32 tiles, one to
+    three low-resolution operands, a 1 x 1 operand)."""
     from eagle_amd import lib
     from oracle import prims as P
-    base = _rand((2, 27, 31, 48), 1)
-    ups = [_rand((2, 14, 16, 48), 2), _rand((2, 7, 8, 48), 3), _rand((2, 4, 4, 48), 4)]
+    n, H, W, c = shape
+    base = _rand(shape, 1)
+    ups = [_rand((n, h, w, c), 2 + i) for i, (h, w) in enumerate(upshapes)]
     q = P.round_f16 if prec == "f16" else (lambda a: a)
     y = q(base)
     for u in ups:
-        y = y + P.upsample_bilinear_ac(q(u), 27, 31)
+        y = y + P.upsample_bilinear_ac(q(u), H, W)
     ref = np.maximum(y, np.float32(0))
     got = lib.op_fuse_sum(base, ups, True, lib.PREC_F32 if prec == "f32" else lib.PREC_F16)
     if prec == "f32":

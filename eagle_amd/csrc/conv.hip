@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, WGS) void conv_f16_ws_kernel(ConvArgs a)
 // Measured (tools/convbench/ad_main.hip, B = 50): 96->96@68x120 83 us (tuned generic kernel 94), 192->192@34x60 70 us (85),
 // 384->384@17x30 67 us (100).
 // ------------------------------------------------------------------------------------------------------------
-template <int CQ, int PG>
+template <int CQ, int PG, bool RES>
 __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
 {
     static_assert(CQ * PG == 4, "four waves per workgroup");
@@ -794,35 +794,29 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
         float4 bias[NT];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) bias[tt] = *(const float4*)(a.bias + co0 + tt * 16 + q * 4);
-        // piece e = i * 64 + lane of a row: pixel e / 6, 16-byte group e % 6
-        int pstrip[3];
-        u32x4 rres[4][3];
-        if (a.r1) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int e = i * 64 + lane, px = e / 6, gq = e - px * 6, ox2 = ox0 + px;
-#pragma unroll
-                for (int r2 = 0; r2 < 4; ++r2) {
-                    const int oy = oy0 + pg * 4 + r2;
-                    const unsigned off = (oy < a.Ho && ox2 < a.Wo) ? (unsigned)((((n * a.Ho + oy) * a.Wo + ox2) * a.r1cs + a.r1off + co0 + gq * 8) * 2) : OOB;
-                    rres[r2][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, off, 0, 0);
-                }
-            }
-        }
-        unsigned poff[4][3];
+        // piece e = i * 64 + lane of a row: pixel e / 6, 16-byte group e % 6.  Offsets are recomputed where they are used (registers are
+        // scarce here); out-of-image pieces get the out-of-range offset (loads return zeros, stores are dropped)
+        int pstrip[3], ppx[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int e = i * 64 + lane, px = e / 6, gq = e - px * 6, ox2 = ox0 + px;
+            const int e = i * 64 + lane, px = e / 6, gq = e - px * 6;
             pstrip[i] = px * RS + gq * 16;
+            ppx[i] = px | (gq << 8);
+        }
+        auto piece_off = [&](int r2, int i, int cs, int off) -> unsigned {
+            const int oy = oy0 + pg * 4 + r2, ox2 = ox0 + (ppx[i] & 0xFF), gq = ppx[i] >> 8;
+            return (oy < a.Ho && ox2 < a.Wo) ? (unsigned)((((n * a.Ho + oy) * a.Wo + ox2) * cs + off + co0 + gq * 8) * 2) : OOB;
+        };
+        u32x4 rres[4][3];
+        if (RES) {
 #pragma unroll
-            for (int r2 = 0; r2 < 4; ++r2) {
-                const int oy = oy0 + pg * 4 + r2;
-                poff[r2][i] = (oy < a.Ho && ox2 < a.Wo) ? (unsigned)((((n * a.Ho + oy) * a.Wo + ox2) * a.ycs + a.yoff + co0 + gq * 8) * 2) : OOB;
-            }
+            for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) rres[r2][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, piece_off(r2, i, a.r1cs, a.r1off), 0, 0);
         }
 #pragma unroll
         for (int r2 = 0; r2 < 4; ++r2) {
-            if (a.r1) {
+            if (RES) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) *(u32x4*)(strip + pstrip[i]) = rres[r2][i];
             }
@@ -833,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
                 for (int tt = 0; tt < NT; ++tt) {
                     char* sp = strip + (xb2 * 16 + lx) * RS + (tt * 16 + q * 4) * 2;
                     float v[4] = {acc[tt][p][0] + bias[tt].x, acc[tt][p][1] + bias[tt].y, acc[tt][p][2] + bias[tt].z, acc[tt][p][3] + bias[tt].w};
-                    if (a.r1) {
+                    if (RES) {
                         const half4 rv = *(const half4*)sp;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
@@ -848,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, poff[r2][i], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, piece_off(r2, i, a.ycs, a.yoff), 0, 0);
         }
     }
 }
@@ -1030,7 +1024,7 @@ static const Inst g_inst[] = {
     {EAGLE_PREC_F16, 3, 1, 96, 3, 6, conv_f16_ws_kernel<96, 3, 4, 1>}, {EAGLE_PREC_F16, 3, 1, 96, 3, 7, conv_f16_ws_kernel<96, 3, 2, 1>},
     {EAGLE_PREC_F16, 3, 1, 96, 2, 7, conv_f16_ws_kernel<96, 2, 2, 1>},
     // A-direct 3x3 stride-1 kernels (variant 8: BN = 192, tile 4 x 32; variant 9: BN = 96, tile 8 x 32); kc = 32
-    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, conv_f16_ad_kernel<4, 1>}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, conv_f16_ad_kernel<2, 2>},
+    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, conv_f16_ad_kernel<4, 1, true>}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, conv_f16_ad_kernel<2, 2, true>},
     // exact fp32 family
     ALLNT32(3, 1, 16), ALLNT32(3, 2, 16), ALLNT32(3, 2, 4), ALLNT32(1, 1, 16),
 };
@@ -1187,10 +1181,11 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         const size_t lim = (size_t)1 << 31;
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(a.ycs, a.r1 ? a.r1cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
-        ensure_max_dynamic_lds((const void*)inst->fn, 160 * 1024);
+        const ConvKernel fn = a.r1 ? inst->fn : (c.variant == 8 ? (ConvKernel)conv_f16_ad_kernel<4, 1, false> : (ConvKernel)conv_f16_ad_kernel<2, 2, false>);
+        ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)
-        hipLaunchKernelGGL(inst->fn, dim3(std::min(items, slots)), dim3(256), lds_bytes(precision, c), s, a);
+        hipLaunchKernelGGL(fn, dim3(std::min(items, slots)), dim3(256), lds_bytes(precision, c), s, a);
         HIP_CHECK(hipGetLastError());
         return;
     }

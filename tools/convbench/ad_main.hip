@@ -108,6 +108,7 @@ __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_ke
 #define TS(var_)
 #endif
     int gc = 0;
+    u32x4 A[3][NT];
     for (int item = item0; item < item_end; ++item) {
         int n, ty, tx, nb; decode(item, n, ty, tx, nb);
         const int oy0 = ty * TH, ox0 = tx * 32;
@@ -116,17 +117,22 @@ __global__ __launch_bounds__(64 * CQ * PG, 512 / (64 * CQ * PG)) void conv_ad_ke
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int p = 0; p < PW; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // A ring: fragments of K-steps kk, kk + 1, kk + 2 (slot = kk % 3; nine K-steps per chunk keep the slots static)
-        u32x4 A[3][NT];
+        // A ring: fragments of K-steps kk, kk + 1, kk + 2 (slot = kk % 3; nine K-steps per chunk keep the slots static).  The ring runs on
+        // across items: the last two requests of an item fetch K-steps 0 and 1 of the NEXT item (its Cout block may differ).
         unsigned wsrc = (unsigned)(nb * nch * 36) * (unsigned)(BN * 16);     // K-step 0 of this item
         const unsigned wend = wsrc + (unsigned)(nch * 9) * KSTEP;
-        auto load_a = [&](int slot) {                      // requests the next K-step of the item (zeros past its end: the descriptor's range check is not used, so clamp)
-            const unsigned so = wsrc < wend ? wsrc : wend - KSTEP;
+        unsigned wnext;
+        { int n2, ty2, tx2, nb2; decode(item + 1 < item_end ? item + 1 : item, n2, ty2, tx2, nb2); wnext = (unsigned)(nb2 * nch * 36) * (unsigned)(BN * 16); }
+        auto load_a = [&](int slot) {
+            const unsigned so = wsrc < wend ? wsrc : wnext + (wsrc - wend);
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) A[slot][tt] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane + tt * 256, so, 0);
             wsrc += KSTEP;
         };
-        load_a(0); load_a(1);
+#ifndef ACONT
+#define ACONT 1
+#endif
+        if (!ACONT || item == item0) { load_a(0); load_a(1); } else wsrc += 2 * KSTEP;
         for (int ch = 0; ch < nch; ++ch, ++gc) {
             // chunk gc has landed (requested one chunk ago); every wave is done with the other slot
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // everything older than the two K-steps of A in flight

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, WGS) void conv_f16_ws_kernel(ConvArgs a)
 // Measured (tools/convbench/ad_main.hip, B = 50): 96->96@68x120 83 us (tuned generic kernel 94), 192->192@34x60 70 us (85),
 // 384->384@17x30 67 us (100).
 // ------------------------------------------------------------------------------------------------------------
-template <int CQ, int PG, bool RES>
+template <int CQ, int PG, bool RES, bool S2>
 __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
 {
     static_assert(CQ * PG == 4, "four waves per workgroup");
@@ -678,7 +678,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NT = 3, PW = 8, NW = 4, BN = CQ * 48, TH = 4 * PG;
     constexpr int KSTEP = 4 * BN * 16;                   // bytes of one K-step (32 input channels of one tap) of the weight image
-    constexpr int HW_ = 34, HPIX = (TH + 2) * HW_, PS = 96;
+    // S2 (stride 2): the input is read as its space-to-depth image (pixel (Y, X) holds the four phases (2Y + ry, 2X + rx) side by side, 4 Cin
+    // channels), on which the 3x3 stride-2 kernel is a 2x2 stride-1 kernel with 7 of its 16 (tap, phase) blocks zero; the re-arrangement
+    // happens in the LDS-DMA addressing, the zeros are in the weight image (conv_tile_weights)
+    constexpr int HW_ = S2 ? 33 : 34, HPIX = (S2 ? TH + 1 : TH + 2) * HW_, PS = 96, KPC = S2 ? 4 : 9, RING = S2 ? 4 : 3;
     constexpr int HSLABS = ((HPIX * PS + 1023) / 1024 + NW - 1) / NW * NW, HB = HSLABS * 1024, HK = HSLABS / NW;
     constexpr int RS = 48 * 2 + 16, STRIP = 32 * RS;     // one output row of the wave (32 pixels x 48 channels) per pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -721,21 +724,31 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
     // ---- halo ring: global chunk index = local item * nch + chunk; slot = index & 1 -------------------------------------------
     int h_g = 0, h_ch = 0, h_item = item0;
     int h_iy0, h_ix0, h_gb;                                // geometry of the item the next request belongs to (scalars)
+    const int cin_s2 = nch * 8;                            // S2: real input channels (the space-to-depth image has 4 * Cin = 32 * nch)
     auto halo_origin = [&](int item) {
         int n, ty, tx, nb; decode(item, n, ty, tx, nb);
         h_iy0 = ty * TH - 1; h_ix0 = tx * 32 - 1;
-        h_gb = (((n * a.H + h_iy0) * a.W + h_ix0) * a.xcs + a.xoff) * 2;
+        h_gb = S2 ? n * a.H : (((n * a.H + h_iy0) * a.W + h_ix0) * a.xcs + a.xoff) * 2;
     };
     halo_origin(h_item);
     auto issue_h = [&]() {
         char* dst = Hb + (h_g & 1) * HB;                  // (past the last chunk: the same requests again, harmlessly, so that the count stays static)
-        const unsigned so = (unsigned)(h_ch * 32) * 2u;
+        const unsigned so = S2 ? 0u : (unsigned)(h_ch * 32) * 2u;
+        const int cb = h_ch * 32, ph0 = S2 ? cb / cin_s2 : 0, r0 = cb - ph0 * cin_s2;      // S2: first phase / channel of this 32-channel chunk (a chunk spans at most two phases)
 #pragma unroll
         for (int k = 0; k < HK; ++k) {
             const int hy = hpk[k] & 0xFF, hx = (hpk[k] >> 8) & 0xFF, slot = (hpk[k] >> 16) & 7;
-            const int iy = h_iy0 + hy, ix = h_ix0 + hx;
-            const unsigned off = (hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                                     ? (unsigned)(h_gb + ((hy * a.W + hx) * a.xcs + slot * 8) * 2) : OOB;
+            unsigned off;
+            if (S2) {
+                const int t = r0 + slot * 8, over = t >= cin_s2 ? 1 : 0, ph = ph0 + over, co = t - over * cin_s2;
+                const int iy = 2 * (h_iy0 + hy) + (ph >> 1), ix = 2 * (h_ix0 + hx) + (ph & 1);
+                off = (hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                          ? (unsigned)((((h_gb + iy) * a.W + ix) * a.xcs + a.xoff + co) * 2) : OOB;
+            } else {
+                const int iy = h_iy0 + hy, ix = h_ix0 + hx;
+                off = (hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                          ? (unsigned)(h_gb + ((hy * a.W + hx) * a.xcs + slot * 8) * 2) : OOB;
+            }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + (wave + NW * k) * 1024), 16, off, so, 0, 0);
         }
         if (h_g + 1 >= GC) return;
@@ -752,10 +765,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int p = 0; p < PW; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // A ring: fragments of K-steps kk, kk + 1, kk + 2 (slot = kk % 3; nine K-steps per chunk keep the slots static)
-        u32x4 A[3][NT];
-        unsigned wsrc = (unsigned)(nb * nch * 36) * (unsigned)(BN * 16);     // K-step 0 of this item
-        const unsigned wend = wsrc + (unsigned)(nch * 9) * KSTEP;
+        // A ring: fragments of K-steps kk, kk + 1, kk + 2 (slot = kk % RING; KPC K-steps per chunk keep the slots static)
+        u32x4 A[RING][NT];
+        unsigned wsrc = (unsigned)(nb * nch * KPC * 4) * (unsigned)(BN * 16);     // K-step 0 of this item
+        const unsigned wend = wsrc + (unsigned)(nch * KPC) * KSTEP;
         auto load_a = [&](int slot) {                      // requests the next K-step of the item (the last two requests of an item repeat its last K-step)
             const unsigned so = wsrc < wend ? wsrc : wend - KSTEP;
 #pragma unroll
@@ -771,21 +784,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
             const char* hb = Hb + (gc & 1) * HB + bbase;
             half8 B[2][PW];
             auto read_b = [&](int slot, int kk) {
-                const int ky = kk / 3, kx = kk - ky * 3;
+                const int ky = S2 ? kk >> 1 : kk / 3, kx = S2 ? kk & 1 : kk - ky * 3;
 #pragma unroll
                 for (int p = 0; p < PW; ++p)
                     B[slot][p] = *(const half8*)(hb + (((p >> 1) + ky) * HW_ + (p & 1) * 16 + kx) * PS);
             };
             read_b(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < 9; ++kk) {
-                load_a((kk + 2) % 3);
-                if (kk + 1 < 9) read_b((kk + 1) & 1, kk + 1);
+            for (int kk = 0; kk < KPC; ++kk) {
+                load_a((kk + 2) % RING);
+                if (kk + 1 < KPC) read_b((kk + 1) & 1, kk + 1);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                     for (int p = 0; p < PW; ++p)
-                        acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16((half8)A[kk % 3][tt], B[kk & 1][p], acc[tt][p], 0, 0, 0);
+                        acc[tt][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16((half8)A[kk % RING][tt], B[kk & 1][p], acc[tt][p], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -964,7 +977,8 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
-static bool conv_ad(const ConvConfig& c) { return c.variant == 8 || c.variant == 9; }      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96)
+static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 11; }      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
+static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
@@ -972,7 +986,7 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
     const int hw = (tw - 1) * c.stride + c.ks, hh = (th - 1) * c.stride + c.ks;
     const int bn = c.nt * 16;
     if (precision == EAGLE_PREC_F16 && conv_ad(c)) {
-        const int pgn = c.variant == 8 ? 1 : 2, slabs = (((4 * pgn + 2) * 34 * 96 + 1023) / 1024 + 3) / 4 * 4;
+        const int pgn = conv_ad_wide(c) ? 1 : 2, slabs = (((c.stride == 2 ? (4 * pgn + 1) * 33 : (4 * pgn + 2) * 34) * 96 + 1023) / 1024 + 3) / 4 * 4;
         return (size_t)2 * slabs * 1024 + 4 * 32 * 112;
     }
     if (precision == EAGLE_PREC_F16) {
@@ -986,7 +1000,7 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
 size_t conv_lds_bytes(int precision, const ConvConfig& c) { return lds_bytes(precision, c); }
 int conv_tiles_per_frame(const ConvConfig& c, int ho, int wo)
 {
-    if (conv_ad(c)) return ((wo + 31) / 32) * ((ho + (c.variant == 8 ? 4 : 8) - 1) / (c.variant == 8 ? 4 : 8));
+    if (conv_ad(c)) return ((wo + 31) / 32) * ((ho + (conv_ad_wide(c) ? 4 : 8) - 1) / (conv_ad_wide(c) ? 4 : 8));
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     return ((wo + tw - 1) / tw) * ((ho + th - 1) / th);
 }
@@ -1024,7 +1038,8 @@ static const Inst g_inst[] = {
     {EAGLE_PREC_F16, 3, 1, 96, 3, 6, conv_f16_ws_kernel<96, 3, 4, 1>}, {EAGLE_PREC_F16, 3, 1, 96, 3, 7, conv_f16_ws_kernel<96, 3, 2, 1>},
     {EAGLE_PREC_F16, 3, 1, 96, 2, 7, conv_f16_ws_kernel<96, 2, 2, 1>},
     // A-direct 3x3 stride-1 kernels (variant 8: BN = 192, tile 4 x 32; variant 9: BN = 96, tile 8 x 32); kc = 32
-    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, conv_f16_ad_kernel<4, 1, true>}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, conv_f16_ad_kernel<2, 2, true>},
+    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, conv_f16_ad_kernel<4, 1, true, false>}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, conv_f16_ad_kernel<2, 2, true, false>},
+    {EAGLE_PREC_F16, 3, 2, 32, 12, 10, conv_f16_ad_kernel<4, 1, true, true>}, {EAGLE_PREC_F16, 3, 2, 32, 6, 11, conv_f16_ad_kernel<2, 2, true, true>},
     // exact fp32 family
     ALLNT32(3, 1, 16), ALLNT32(3, 2, 16), ALLNT32(3, 2, 4), ALLNT32(1, 1, 16),
 };
@@ -1069,6 +1084,13 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 8; } else { q.nt = 6; q.variant = 9; }
         return q;
     }
+    // 3x3 stride-2 layers with the same Cout: the A-direct kernel over the space-to-depth image (EAGLE_CONV_AD2=0: off)
+    static const bool ad2_on = !(getenv("EAGLE_CONV_AD2") && atoi(getenv("EAGLE_CONV_AD2")) == 0);
+    if (ad_on && ad2_on && plain_epilogue && ks == 3 && stride == 2 && cin_pad % 8 == 0 && cin_pad >= 32 && cout_pad % 96 == 0) {
+        ConvConfig q = c; q.kc = 32;
+        if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 10; } else { q.nt = 6; q.variant = 11; }
+        return q;
+    }
     // fp16: per-layer table measured on MI355X (tools/autotune_conv.py); shapes not in the table use the heuristic below
     for (const Tuned& t : g_tuned)
         if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
@@ -1096,6 +1118,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
 
 size_t conv_weight_elems(int precision, const ConvConfig& c)
 {
+    if (precision == EAGLE_PREC_F16 && conv_ad(c) && c.stride == 2) return (size_t)(c.cout_pad / (c.nt * 16)) * (4 * c.cin / 32) * 16 * (c.nt * 16) * 8;
     const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc;
     if (precision == EAGLE_PREC_F16) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 4 * bn * 8;
     return (size_t)nblk * nch * c.ks * c.ks * (c.kc / 4) * 4 * bn;
@@ -1107,6 +1130,23 @@ void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int c
     auto W = [&](int tap, int ci, int co) -> float {
         return (ci < cin_real && co < cout_real) ? w[((size_t)tap * cin_real + ci) * cout_real + co] : 0.0f;
     };
+    if (precision == EAGLE_PREC_F16 && conv_ad(c) && c.stride == 2) {
+        // space-to-depth form: [Cout block][chunk of 32 s2d channels][tap' (2x2) * 4 + channel group][BN][8]; s2d channel = phase * Cin + channel,
+        // phase = 2 * ry + rx; tap' row 0 is the s2d row above (only its odd phase contributes: ky = 0), tap' row 1 the same row (ky = 1, 2)
+        _Float16* d = (_Float16*)dst;
+        const int nch2 = 4 * c.cin / 32;
+        for (int b = 0; b < nblk; ++b)
+            for (int ch = 0; ch < nch2; ++ch)
+                for (int g = 0; g < 16; ++g)
+                    for (int nn = 0; nn < bn; ++nn)
+                        for (int j = 0; j < 8; ++j) {
+                            const int tp = g / 4, cg = g % 4, tyy = tp >> 1, txx = tp & 1;
+                            const int sc = ch * 32 + cg * 8 + j, ph = sc / c.cin, ci = sc - ph * c.cin, ry = ph >> 1, rx = ph & 1;
+                            const int ky = tyy == 0 ? (ry == 1 ? 0 : -1) : (ry == 0 ? 1 : 2), kx = txx == 0 ? (rx == 1 ? 0 : -1) : (rx == 0 ? 1 : 2);
+                            *d++ = (_Float16)((ky < 0 || kx < 0) ? 0.f : W(ky * 3 + kx, ci, b * bn + nn));
+                        }
+        return;
+    }
     if (precision == EAGLE_PREC_F16) {
         const int G = c.kc / 8, NGR = taps * G, NI = f16_ni(c.ks, c.kc);
         _Float16* d = (_Float16*)dst;
@@ -1173,15 +1213,17 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
-        if (a.out_f32 || a.r2 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != 32 || c.ks != 3 || c.stride != 1)
-            fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3 stride 1, kc = 32, fp16 output, at most one residual, pre_act none, post_act in {none, ReLU}");
-        const int thh = c.variant == 8 ? 4 : 8;
+        if (a.out_f32 || a.r2 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != 32 || c.ks != 3 || c.stride != (c.variant >= 10 ? 2 : 1))
+            fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32, fp16 output, at most one residual, pre_act none, post_act in {none, ReLU}");
+        if (c.stride == 2) a.nchunks = 4 * c.cin / 32;      // chunks of the space-to-depth image
+        const int thh = conv_ad_wide(c) ? 4 : 8;
         a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + thh - 1) / thh;
         a.gy = c.cout_pad / (c.nt * 16);
         const size_t lim = (size_t)1 << 31;
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(a.ycs, a.r1 ? a.r1cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
-        const ConvKernel fn = a.r1 ? inst->fn : (c.variant == 8 ? (ConvKernel)conv_f16_ad_kernel<4, 1, false> : (ConvKernel)conv_f16_ad_kernel<2, 2, false>);
+        const ConvKernel fn = a.r1 ? inst->fn : c.variant == 8 ? (ConvKernel)conv_f16_ad_kernel<4, 1, false, false> : c.variant == 9 ? (ConvKernel)conv_f16_ad_kernel<2, 2, false, false>
+                                         : c.variant == 10 ? (ConvKernel)conv_f16_ad_kernel<4, 1, false, true> : (ConvKernel)conv_f16_ad_kernel<2, 2, false, true>;
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)

@@ -76,7 +76,7 @@ size_t conv_lds_bytes(int precision, const ConvConfig& cfg);
 // w_hwio: folded fp32 weights [ks][ks][cin_real][cout_real]; dst: host buffer of conv_weight_elems elements
 void conv_tile_weights(int precision, const ConvConfig& cfg, const float* w_hwio, int cin_real, int cout_real, void* dst);
 // plain_epilogue: pre_act none, post_act none/ReLU, at most one residual, fp16 output (what the weight-stationary kernel implements)
-ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue = false);
+ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue = false, bool second_residual = false);
 
 // ---- other kernels ----------------------------------------------------------------------------------------
 struct LetterBox { int new_h, new_w, top, left, out_h, out_w; };

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, WGS) void conv_f16_ws_kernel(ConvArgs a)
 // Measured (tools/convbench/ad_main.hip, B = 50): 96->96@68x120 83 us (tuned generic kernel 94), 192->192@34x60 70 us (85),
 // 384->384@17x30 67 us (100).
 // ------------------------------------------------------------------------------------------------------------
-template <int CQ, int PG, bool RES, bool S2>
+template <int CQ, int PG, int RES, bool S2>          // RES: number of residual operands (0, 1, 2)
 __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
 {
     static_assert(CQ * PG == 4, "four waves per workgroup");
@@ -704,6 +704,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
     const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0x7FFFFFFF, 0x00020000);
     const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7FFFFFFF, 0x00020000);
     const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.r1, 0, 0x7FFFFFFF, 0x00020000);
+    const rsrc_t rrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.r2, 0, 0x7FFFFFFF, 0x00020000);
     const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0x7FFFFFFF, 0x00020000);
     int hpk[HK];                                          // per slab: halo row | column << 8 | channel slot << 16, or -1 (padding)
 #pragma unroll
@@ -820,39 +821,64 @@ __global__ __launch_bounds__(256, 2) void conv_f16_ad_kernel(ConvArgs a)
             const int oy = oy0 + pg * 4 + r2, ox2 = ox0 + (ppx[i] & 0xFF), gq = ppx[i] >> 8;
             return (oy < a.Ho && ox2 < a.Wo) ? (unsigned)((((n * a.Ho + oy) * a.Wo + ox2) * cs + off + co0 + gq * 8) * 2) : OOB;
         };
-        u32x4 rres[4][3];
-        if (RES) {
+        u32x4 rres[4][3], rres2[4][3];
+        if (RES >= 1) {
 #pragma unroll
             for (int r2 = 0; r2 < 4; ++r2)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) rres[r2][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, piece_off(r2, i, a.r1cs, a.r1off), 0, 0);
         }
+        if (RES >= 2) {
+#pragma unroll
+            for (int r2 = 0; r2 < 4; ++r2)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) rres2[r2][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs2, piece_off(r2, i, a.r2cs, a.r2off), 0, 0);
+        }
 #pragma unroll
         for (int r2 = 0; r2 < 4; ++r2) {
-            if (RES) {
+            if (RES >= 1) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) *(u32x4*)(strip + pstrip[i]) = rres[r2][i];
             }
+            float v[2][NT][4];
 #pragma unroll
             for (int xb2 = 0; xb2 < 2; ++xb2) {
                 const int p = r2 * 2 + xb2;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    char* sp = strip + (xb2 * 16 + lx) * RS + (tt * 16 + q * 4) * 2;
-                    float v[4] = {acc[tt][p][0] + bias[tt].x, acc[tt][p][1] + bias[tt].y, acc[tt][p][2] + bias[tt].z, acc[tt][p][3] + bias[tt].w};
-                    if (RES) {
+                    const char* sp = strip + (xb2 * 16 + lx) * RS + (tt * 16 + q * 4) * 2;
+                    v[xb2][tt][0] = acc[tt][p][0] + bias[tt].x; v[xb2][tt][1] = acc[tt][p][1] + bias[tt].y;
+                    v[xb2][tt][2] = acc[tt][p][2] + bias[tt].z; v[xb2][tt][3] = acc[tt][p][3] + bias[tt].w;
+                    if (RES >= 1) {
                         const half4 rv = *(const half4*)sp;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (float)rv[r] + v[r];
+                        for (int r = 0; r < 4; ++r) v[xb2][tt][r] = (float)rv[r] + v[xb2][tt][r];
                     }
-                    if (a.post_act == 1) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-                    }
-                    half4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    *(half4*)sp = o;
                 }
             }
+            if (RES >= 2) {                                 // second residual through the same strip (LDS operations of a wave execute in order)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) *(u32x4*)(strip + pstrip[i]) = rres2[r2][i];
+#pragma unroll
+                for (int xb2 = 0; xb2 < 2; ++xb2)
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const half4 rv = *(const half4*)(strip + (xb2 * 16 + lx) * RS + (tt * 16 + q * 4) * 2);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[xb2][tt][r] = v[xb2][tt][r] + (float)rv[r];
+                    }
+            }
+#pragma unroll
+            for (int xb2 = 0; xb2 < 2; ++xb2)
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    if (a.post_act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[xb2][tt][r] = v[xb2][tt][r] > 0.f ? v[xb2][tt][r] : 0.f;
+                    }
+                    half4 o = {(_Float16)v[xb2][tt][0], (_Float16)v[xb2][tt][1], (_Float16)v[xb2][tt][2], (_Float16)v[xb2][tt][3]};
+                    *(half4*)(strip + (xb2 * 16 + lx) * RS + (tt * 16 + q * 4) * 2) = o;
+                }
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, piece_off(r2, i, a.ycs, a.yoff), 0, 0);
@@ -1038,8 +1064,8 @@ static const Inst g_inst[] = {
     {EAGLE_PREC_F16, 3, 1, 96, 3, 6, conv_f16_ws_kernel<96, 3, 4, 1>}, {EAGLE_PREC_F16, 3, 1, 96, 3, 7, conv_f16_ws_kernel<96, 3, 2, 1>},
     {EAGLE_PREC_F16, 3, 1, 96, 2, 7, conv_f16_ws_kernel<96, 2, 2, 1>},
     // A-direct 3x3 stride-1 kernels (variant 8: BN = 192, tile 4 x 32; variant 9: BN = 96, tile 8 x 32); kc = 32
-    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, conv_f16_ad_kernel<4, 1, true, false>}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, conv_f16_ad_kernel<2, 2, true, false>},
-    {EAGLE_PREC_F16, 3, 2, 32, 12, 10, conv_f16_ad_kernel<4, 1, true, true>}, {EAGLE_PREC_F16, 3, 2, 32, 6, 11, conv_f16_ad_kernel<2, 2, true, true>},
+    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, conv_f16_ad_kernel<4, 1, 1, false>}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, conv_f16_ad_kernel<2, 2, 1, false>},
+    {EAGLE_PREC_F16, 3, 2, 32, 12, 10, conv_f16_ad_kernel<4, 1, 1, true>}, {EAGLE_PREC_F16, 3, 2, 32, 6, 11, conv_f16_ad_kernel<2, 2, 1, true>},
     // exact fp32 family
     ALLNT32(3, 1, 16), ALLNT32(3, 2, 16), ALLNT32(3, 2, 4), ALLNT32(1, 1, 16),
 };
@@ -1057,8 +1083,11 @@ static const Tuned g_tuned[] = {
 #include "conv_tuned.inc"
     {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
-ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue)
+ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue, bool second_residual)
 {
+    // plain_epilogue: no activation before the residual adds, none / ReLU after them, fp16 output.  The weight-stationary kernels also need
+    // at most one residual; the A-direct kernels take two.
+    const bool plain_one = plain_epilogue && !second_residual;
     ConvConfig c;
     c.ks = ks; c.stride = stride; c.cin = cin_pad; c.cout_pad = cout_pad;
     c.wx = (wo > 16) ? 2 : 1;
@@ -1074,7 +1103,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
     if (const char* f = getenv("EAGLE_CONV_FORCE")) {
         ConvConfig q = c;
         if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 &&
-            find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024 && ((!conv_ws(q) && !conv_ad(q)) || plain_epilogue))
+            find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024 && (conv_ws(q) ? plain_one : conv_ad(q) ? plain_epilogue : true))
             return q;
     }
     // 3x3 stride-1 layers whose Cout is a multiple of 96 (HRNet's 96 / 192 / 384-channel branches): the A-direct kernel (EAGLE_CONV_AD=0: off)
@@ -1095,7 +1124,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
     for (const Tuned& t : g_tuned)
         if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
             ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = t.variant;
-            if (conv_ws(q) && !plain_epilogue) continue;   // the weight-stationary kernel has no SiLU / second-residual / fp32-output epilogue
+            if (conv_ws(q) && !plain_one) continue;   // the weight-stationary kernel has no SiLU / second-residual / fp32-output epilogue
             if (find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
         }
     // heuristic: the (NT, KC) pair with the most work per staged item whose LDS footprint still lets two workgroups share a CU
@@ -1205,6 +1234,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.y = L.y.p; a.ycs = L.y.cs; a.yoff = L.y.off; a.Ho = L.y.h; a.Wo = L.y.w;
     a.r1 = L.r1.p; a.r1cs = L.r1.cs; a.r1off = L.r1.off;
     a.r2 = L.r2.p; a.r2cs = L.r2.cs; a.r2off = L.r2.off;
+    if (!a.r1 && a.r2) { a.r1 = a.r2; a.r1cs = a.r2cs; a.r1off = a.r2off; a.r2 = nullptr; }       // a single residual is always operand 1 (IEEE addition is commutative: same bits)
     a.pre_act = L.pre_act; a.post_act = L.post_act; a.out_f32 = L.out_f32 || precision == EAGLE_PREC_F32;
     a.wx = c.wx;
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
@@ -1213,17 +1243,22 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
-        if (a.out_f32 || a.r2 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != 32 || c.ks != 3 || c.stride != (c.variant >= 10 ? 2 : 1))
-            fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32, fp16 output, at most one residual, pre_act none, post_act in {none, ReLU}");
+        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != 32 || c.ks != 3 || c.stride != (c.variant >= 10 ? 2 : 1))
+            fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32, fp16 output, pre_act none, post_act in {none, ReLU}");
         if (c.stride == 2) a.nchunks = 4 * c.cin / 32;      // chunks of the space-to-depth image
         const int thh = conv_ad_wide(c) ? 4 : 8;
         a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + thh - 1) / thh;
         a.gy = c.cout_pad / (c.nt * 16);
         const size_t lim = (size_t)1 << 31;
-        if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(a.ycs, a.r1 ? a.r1cs : 0) * 2 >= lim)
+        if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
-        const ConvKernel fn = a.r1 ? inst->fn : c.variant == 8 ? (ConvKernel)conv_f16_ad_kernel<4, 1, false, false> : c.variant == 9 ? (ConvKernel)conv_f16_ad_kernel<2, 2, false, false>
-                                         : c.variant == 10 ? (ConvKernel)conv_f16_ad_kernel<4, 1, false, true> : (ConvKernel)conv_f16_ad_kernel<2, 2, false, true>;
+        const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
+        static const ConvKernel ad_fn[4][3] = {
+            {conv_f16_ad_kernel<4, 1, 0, false>, conv_f16_ad_kernel<4, 1, 1, false>, conv_f16_ad_kernel<4, 1, 2, false>},
+            {conv_f16_ad_kernel<2, 2, 0, false>, conv_f16_ad_kernel<2, 2, 1, false>, conv_f16_ad_kernel<2, 2, 2, false>},
+            {conv_f16_ad_kernel<4, 1, 0, true>, conv_f16_ad_kernel<4, 1, 1, true>, conv_f16_ad_kernel<4, 1, 2, true>},
+            {conv_f16_ad_kernel<2, 2, 0, true>, conv_f16_ad_kernel<2, 2, 1, true>, conv_f16_ad_kernel<2, 2, 2, true>}};
+        const ConvKernel fn = ad_fn[c.variant - 8][nres];
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)

@@ -78,14 +78,14 @@ def test_conv_weight_stationary_variants(force, cin, cout, shape, monkeypatch):
 
 @pytest.mark.parametrize("cin,cout", [(96, 96), (192, 192), (64, 192), (384, 384), (32, 96)])
 @pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (5, 17, 30), (1, 68, 120)])
-@pytest.mark.parametrize("res,post", [(True, 1), (False, 1), (False, 0)])
+@pytest.mark.parametrize("res,post", [(True, 1), (False, 1), (False, 0), (2, 1)])
 def test_conv_a_direct_variants(cin, cout, shape, res, post):
     _a_direct_case(cin, cout, shape, res, post, 1)
 
 
 @pytest.mark.parametrize("cin,cout", [(48, 96), (96, 192), (256, 96), (192, 384), (48, 192), (96, 96), (40, 96)])
 @pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (2, 135, 240), (3, 34, 61), (1, 1, 1)])
-@pytest.mark.parametrize("res,post", [(True, 1), (False, 0)])
+@pytest.mark.parametrize("res,post", [(True, 1), (False, 0), (2, 1), (2, 0)])
 def test_conv_a_direct_stride2(cin, cout, shape, res, post):
     """The stride-2 form (variants 10 / 11: the kernel runs on the space-to-depth image, re-arranged by the LDS-DMA addressing): odd and
     even input sizes, partial tiles, Cin that is not a multiple of 32 (chunks spanning two phases), a 1 x 1 input."""
@@ -108,9 +108,10 @@ def _a_direct_case(cin, cout, shape, res, post, stride):
     wt = _rand((3, 3, cin, cout), 22, (2.0 / (cin * 9)) ** 0.5)
     b = _rand((cout,), 23, 0.1)
     r1 = _rand((n, ho, wo, cout), 24) if res else None
+    r2 = _rand((n, ho, wo, cout), 25) if res == 2 else None          # res: False / True / 2 = number of residual operands
     q = P.round_f16
-    ref = P.conv2d(q(x), q(wt), b, stride=stride, pre=0, r1=q(r1) if res else None, r2=None, post=post, f16_out=True)
-    got = lib.op_conv2d(x, wt, b, stride, 0, r1, None, post, lib.PREC_F16)
+    ref = P.conv2d(q(x), q(wt), b, stride=stride, pre=0, r1=q(r1) if res else None, r2=q(r2) if res == 2 else None, post=post, f16_out=True)
+    got = lib.op_conv2d(x, wt, b, stride, 0, r1, r2, post, lib.PREC_F16)
     err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
     assert err < F16_TOL, f"fp16 A-direct conv error {err}"
 

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extras --cadence 25 > $O/prof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1
+cd $R && python3 -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/conv_hbm_traffic.json --steps 2 --warmup 0 --no-cpu-baseline
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete
 ls -R $O | head -30

@@ -3,10 +3,9 @@
 // One workgroup per crop: 2-means segmentation of the crop's RGB pixels (the reference calls scikit-learn's KMeans(n_clusters=2,
 // random_state=0)), the cluster that owns the majority of the four crop corners is the background, and the other cluster's pixels are
 // counted per colour range of proc.py:10-23 in cv2's 8-bit HSV (hue 0..180, table-driven fixed point like hue180 in geom.hip).
-// Deviation, stated: instead of ONE k-means++ start drawn from numpy's RandomState(0), Lloyd's iterations run to their fixed point (exact
-// integer sums) from TWO deterministic starts (farthest-point pair; principal-axis split) and the partition with the smaller
-// within-cluster sum of squares is kept.  Measured against the reference's own outputs (tests/golden/team_golden.json, sklearn's real
-// KMeans): 105 of 108 crops identical in every count; the other three have two fixed points and sklearn's random start picked the worse.
+// The 2-means is scikit-learn's run restated step by step (k-means++ seeding with RandomState(0)'s first three doubles, Lloyd's iterations with
+// the tol rule, final assignment; oracle/colors.py::kmeans2_labels is the same restatement and is pinned to sklearn's own labels on
+// several hundred crops): colour counts identical to the reference's own outputs on all crops of tests/golden/team_golden.json.
 #include "common.h"
 
 namespace eagle {
@@ -38,7 +37,6 @@ struct TeamArgs { const uint8_t* bgr; int n_frames, fh, fw; const EagleCrop* cro
 __global__ __launch_bounds__(256) void team_color_kernel(TeamArgs a)
 {
     __shared__ unsigned long long s_sum[8];          // per cluster: r, g, b, count
-    __shared__ unsigned long long s_best; __shared__ unsigned s_idx;
     __shared__ double s_c[2][3];
     __shared__ int s_cnt[12];
     __shared__ int s_flag;
@@ -55,153 +53,120 @@ __global__ __launch_bounds__(256) void team_color_kernel(TeamArgs a)
         const uint8_t* p = base + ((size_t)yy * a.fw + xx) * 3;
         *b = p[0]; *g = p[1]; *r = p[2];
     };
-    // (A) mean, as integer sums
+    // (A) k-means++ seeding exactly as scikit-learn 1.7 runs it for KMeans(n_clusters=2, random_state=0): RandomState(0) is created per call,
+    //     so its first three doubles are constants.  centre 0 = X[choice(n)] = X[floor(u0 * n)]; two candidates for centre 1 at the
+    //     quantiles u1, u2 of the cumulative squared distance to centre 0 (searchsorted, side = left); the candidate with the smaller
+    //     potential wins.  Distances between pixels are exact integers, so the cumulative sums and potentials are exact.
+    constexpr double U0 = 0.5488135039273248, U1 = 0.7151893663724195, U2 = 0.6027633760716439;
+    __shared__ unsigned long long s_part[256];
+    __shared__ int s_cand[2];
+    __shared__ unsigned long long s_pot[2];
+    int i0 = (int)floor(U0 * (double)n); if (i0 > n - 1) i0 = n - 1;
+    int c0r_, c0g_, c0b_; px(i0, &c0r_, &c0g_, &c0b_);
+    const int chunk = (n + 255) / 256, lo = tid * chunk, hi = min(n, lo + chunk);
+    auto dist0 = [&](int i) -> unsigned long long {
+        int r, g, b; px(i, &r, &g, &b);
+        const long long dr = r - c0r_, dg = g - c0g_, db = b - c0b_;
+        return (unsigned long long)(dr * dr + dg * dg + db * db);
+    };
+    {
+        unsigned long long ps = 0;
+        for (int i = lo; i < hi; ++i) ps += dist0(i);
+        s_part[tid] = ps;
+    }
     if (tid < 8) s_sum[tid] = 0;
     __syncthreads();
-    {
-        unsigned long long sr = 0, sg = 0, sb = 0;
-        for (int i = tid; i < n; i += 256) { int r, g, b; px(i, &r, &g, &b); sr += r; sg += g; sb += b; }
-        atomicAdd(&s_sum[0], sr); atomicAdd(&s_sum[1], sg); atomicAdd(&s_sum[2], sb);
+    if (tid < 2) {                                        // thread t finds candidate t: first index whose cumulative distance reaches u * potential
+        unsigned long long pot = 0;
+        for (int k = 0; k < 256; ++k) pot += s_part[k];
+        const double val = (tid == 0 ? U1 : U2) * (double)pot;
+        unsigned long long cum = 0; int k = 0;
+        while (k < 255 && (double)(cum + s_part[k]) < val) { cum += s_part[k]; ++k; }
+        int i = k * chunk; const int e = min(n, i + chunk);
+        for (; i < e; ++i) { cum += dist0(i); if ((double)cum >= val) break; }
+        s_cand[tid] = min(i, n - 1);
+        s_pot[tid] = 0;
     }
     __syncthreads();
-    const long long SR = (long long)s_sum[0], SG = (long long)s_sum[1], SB = (long long)s_sum[2];
-    // (B) first centre: the pixel farthest from the mean (n^2 * distance^2 in exact integers; ties: lowest index); (C) second: farthest from it
-    int cr[2] = {0, 0}, cg[2] = {0, 0}, cb[2] = {0, 0};
-    for (int pass = 0; pass < 2; ++pass) {
-        if (tid == 0) { s_best = 0; s_idx = 0xFFFFFFFFu; }
-        __syncthreads();
-        unsigned long long best = 0;
-        for (int i = tid; i < n; i += 256) {
-            int r, g, b; px(i, &r, &g, &b);
-            long long dr, dg, db;
-            if (pass == 0) { dr = (long long)n * r - SR; dg = (long long)n * g - SG; db = (long long)n * b - SB; }
-            else { dr = r - cr[0]; dg = g - cg[0]; db = b - cb[0]; }
-            const unsigned long long d = (unsigned long long)(dr * dr + dg * dg + db * db);
-            if (d > best) best = d;
-        }
-        atomicMax(&s_best, best);
-        __syncthreads();
-        const unsigned long long gb = s_best;
-        for (int i = tid; i < n; i += 256) {
-            int r, g, b; px(i, &r, &g, &b);
-            long long dr, dg, db;
-            if (pass == 0) { dr = (long long)n * r - SR; dg = (long long)n * g - SG; db = (long long)n * b - SB; }
-            else { dr = r - cr[0]; dg = g - cg[0]; db = b - cb[0]; }
-            if ((unsigned long long)(dr * dr + dg * dg + db * db) == gb) { atomicMin(&s_idx, (unsigned)i); break; }
-        }
-        __syncthreads();
-        { int r, g, b; px((int)s_idx, &r, &g, &b); cr[pass] = r; cg[pass] = g; cb[pass] = b; }
-        __syncthreads();
-    }
-    // (D) Lloyd's iterations to the fixed point (centres are ratios of exact integer sums, so "unchanged" is an exact test), from two
-    // deterministic starts: the farthest-point pair above, and the two halves of the crop split along its principal colour axis (a thin
-    // bright line through the crop attracts the farthest-point start; k-means++ weights by mass, the principal-axis start does too).
-    // The converged pair with the smaller within-cluster sum of squares is kept.
-    __shared__ double s_try[2][2][3]; __shared__ double s_sse[2];
-    __shared__ unsigned long long s_cov[6];
-    if (tid < 6) s_cov[tid] = 0;
-    __syncthreads();
     {
+        int ar, ag, ab, br, bg, bb; px(s_cand[0], &ar, &ag, &ab); px(s_cand[1], &br, &bg, &bb);
+        unsigned long long pa = 0, pb = 0;
+        for (int i = tid; i < n; i += 256) {
+            int r, g, b; px(i, &r, &g, &b);
+            const unsigned long long d0 = dist0(i);
+            const long long x1 = r - ar, y1 = g - ag, z1 = b - ab, x2 = r - br, y2 = g - bg, z2 = b - bb;
+            const unsigned long long da = (unsigned long long)(x1 * x1 + y1 * y1 + z1 * z1), db2 = (unsigned long long)(x2 * x2 + y2 * y2 + z2 * z2);
+            pa += da < d0 ? da : d0; pb += db2 < d0 ? db2 : d0;
+        }
+        atomicAdd(&s_pot[0], pa); atomicAdd(&s_pot[1], pb);
+        // per-channel sums for the tolerance (mean of the channel variances * 1e-4)
         unsigned long long q[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = tid; i < n; i += 256) { int r, g, b; px(i, &r, &g, &b); q[0] += r * r; q[1] += g * g; q[2] += b * b; q[3] += r * g; q[4] += r * b; q[5] += g * b; }
-        for (int k = 0; k < 6; ++k) atomicAdd(&s_cov[k], q[k]);
+        for (int i = tid; i < n; i += 256) { int r, g, b; px(i, &r, &g, &b); q[0] += r; q[1] += g; q[2] += b; q[3] += r * r; q[4] += g * g; q[5] += b * b; }
+        for (int k = 0; k < 6; ++k) atomicAdd(&s_sum[k], q[k]);
     }
     __syncthreads();
+    __shared__ double s_prev[2][3];
+    __shared__ double s_tol;
+    __shared__ unsigned s_changed;
     if (tid == 0) {
-        const double N = n, mr = SR / N, mg = SG / N, mb = SB / N;
-        const double C[3][3] = {{s_cov[0] / N - mr * mr, s_cov[3] / N - mr * mg, s_cov[4] / N - mr * mb},
-                                {s_cov[3] / N - mr * mg, s_cov[1] / N - mg * mg, s_cov[5] / N - mg * mb},
-                                {s_cov[4] / N - mr * mb, s_cov[5] / N - mg * mb, s_cov[2] / N - mb * mb}};
-        double v[3] = {1.0, 1.0, 1.0};
-        for (int it = 0; it < 32; ++it) {
-            double u[3];
-            for (int i = 0; i < 3; ++i) u[i] = C[i][0] * v[0] + C[i][1] * v[1] + C[i][2] * v[2];
-            const double nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-            if (!(nn > 0)) break;
-            for (int i = 0; i < 3; ++i) v[i] = u[i] / nn;
-        }
-        s_try[1][0][0] = v[0]; s_try[1][0][1] = v[1]; s_try[1][0][2] = v[2];      // (axis, handed to the split pass below)
-        s_try[1][1][0] = mr; s_try[1][1][1] = mg; s_try[1][1][2] = mb;
+        const int i1 = s_cand[s_pot[1] < s_pot[0] ? 1 : 0];
+        int r, g, b; px(i1, &r, &g, &b);
+        s_c[0][0] = c0r_; s_c[0][1] = c0g_; s_c[0][2] = c0b_;
+        s_c[1][0] = r; s_c[1][1] = g; s_c[1][2] = b;
+        double var = 0.0;
+        for (int j = 0; j < 3; ++j) { const double m = (double)s_sum[j] / (double)n; var += (double)s_sum[3 + j] / (double)n - m * m; }
+        s_tol = var / 3.0 * 1e-4;
+        for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) s_prev[k][j] = -1.0;     // no previous assignment: the first iteration cannot be "unchanged"
     }
-    if (tid < 8) s_sum[tid] = 0;
     __syncthreads();
-    {
-        const double ax = s_try[1][0][0], ay = s_try[1][0][1], az = s_try[1][0][2], mr = s_try[1][1][0], mg = s_try[1][1][1], mb = s_try[1][1][2];
+    // (B) Lloyd's iterations as sklearn's _kmeans_single_lloyd runs them (float64; label = argmin_k |c_k|^2 - 2 x.c_k, ties to cluster 0): stop when
+    //     the assignment repeats, or when the summed squared centre shift is <= tol; at most 300 iterations.  The final labels are the
+    //     assignment to the final centres either way.
+    auto assign = [&](int r, int g, int b, const double (*C)[3]) -> int {
+        const double e0 = (C[0][0] * C[0][0] + C[0][1] * C[0][1] + C[0][2] * C[0][2]) - 2.0 * (r * C[0][0] + g * C[0][1] + b * C[0][2]);
+        const double e1 = (C[1][0] * C[1][0] + C[1][1] * C[1][1] + C[1][2] * C[1][2]) - 2.0 * (r * C[1][0] + g * C[1][1] + b * C[1][2]);
+        return e1 < e0 ? 1 : 0;
+    };
+    for (int it = 0; it < 300; ++it) {
+        if (tid < 8) s_sum[tid] = 0;
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        const bool have_prev = it > 0;
         unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned changed = 0;
         for (int i = tid; i < n; i += 256) {
             int r, g, b; px(i, &r, &g, &b);
-            const int l = ((r - mr) * ax + (g - mg) * ay + (b - mb) * az) > 0.0 ? 4 : 0;
-            acc[l] += r; acc[l + 1] += g; acc[l + 2] += b; acc[l + 3] += 1;
+            const int l = assign(r, g, b, s_c);
+            if (!have_prev || assign(r, g, b, s_prev) != l) changed = 1;
+            acc[4 * l] += r; acc[4 * l + 1] += g; acc[4 * l + 2] += b; acc[4 * l + 3] += 1;
         }
         for (int k = 0; k < 8; ++k) if (acc[k]) atomicAdd(&s_sum[k], acc[k]);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int k = 0; k < 2; ++k) { s_try[0][k][0] = cr[k]; s_try[0][k][1] = cg[k]; s_try[0][k][2] = cb[k]; }
-        for (int k = 0; k < 2; ++k) {
-            const unsigned long long cnt = s_sum[4 * k + 3];
-            for (int j = 0; j < 3; ++j) s_try[1][k][j] = cnt ? (double)s_sum[4 * k + j] / (double)cnt : (double)(k ? cr[1] : cr[0]);
-        }
-    }
-    __syncthreads();
-    for (int start = 0; start < 2; ++start) {
-        if (tid == 0) for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) s_c[k][j] = s_try[start][k][j];
+        if (changed) atomicOr(&s_changed, 1u);
         __syncthreads();
-        for (int it = 0; it < 100; ++it) {
-            if (tid < 8) s_sum[tid] = 0;
-            if (tid == 0) s_flag = 0;
-            __syncthreads();
-            const double c0r = s_c[0][0], c0g = s_c[0][1], c0b = s_c[0][2], c1r = s_c[1][0], c1g = s_c[1][1], c1b = s_c[1][2];
-            unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = tid; i < n; i += 256) {
-                int r, g, b; px(i, &r, &g, &b);
-                const double d0 = (r - c0r) * (r - c0r) + (g - c0g) * (g - c0g) + (b - c0b) * (b - c0b);
-                const double d1 = (r - c1r) * (r - c1r) + (g - c1g) * (g - c1g) + (b - c1b) * (b - c1b);
-                const int l = d1 < d0 ? 4 : 0;
-                acc[l] += r; acc[l + 1] += g; acc[l + 2] += b; acc[l + 3] += 1;
-            }
-            for (int k = 0; k < 8; ++k) if (acc[k]) atomicAdd(&s_sum[k], acc[k]);
-            __syncthreads();
-            if (tid == 0) {
-                int changed = 0;
-                for (int k = 0; k < 2; ++k) {
-                    const unsigned long long cnt = s_sum[4 * k + 3];
-                    if (!cnt) continue;
-                    for (int j = 0; j < 3; ++j) {
-                        const double v = (double)s_sum[4 * k + j] / (double)cnt;
-                        if (v != s_c[k][j]) { s_c[k][j] = v; changed = 1; }
-                    }
-                }
-                s_flag = changed;
-            }
-            __syncthreads();
-            if (!s_flag) break;
-        }
-        // within-cluster sum of squares of this fixed point: sum |p|^2 - sum_k count_k |c_k|^2 (exact sums, double arithmetic in one thread)
         if (tid == 0) {
-            double sse = (double)s_cov[0] + (double)s_cov[1] + (double)s_cov[2];
-            for (int k = 0; k < 2; ++k) sse -= (double)s_sum[4 * k + 3] * (s_c[k][0] * s_c[k][0] + s_c[k][1] * s_c[k][1] + s_c[k][2] * s_c[k][2]);
-            s_sse[start] = sse;
-            for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) s_try[start][k][j] = s_c[k][j];
+            double shift = 0.0;
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long cnt = s_sum[4 * k + 3];
+                for (int j = 0; j < 3; ++j) {
+                    const double v = cnt ? (double)s_sum[4 * k + j] / (double)cnt : s_c[k][j];
+                    shift += (v - s_c[k][j]) * (v - s_c[k][j]);
+                    s_prev[k][j] = s_c[k][j];
+                    s_c[k][j] = v;
+                }
+            }
+            s_flag = (!s_changed || shift <= s_tol) ? 0 : 1;
         }
         __syncthreads();
+        if (!s_flag) break;
     }
-    if (tid == 0) {
-        const int best = s_sse[1] < s_sse[0] ? 1 : 0;
-        for (int k = 0; k < 2; ++k) for (int j = 0; j < 3; ++j) s_c[k][j] = s_try[best][k][j];
-    }
-    __syncthreads();
     // (E) corner vote -> background cluster; (F) colour-range counts of the other cluster's pixels
-    const double c0r = s_c[0][0], c0g = s_c[0][1], c0b = s_c[0][2], c1r = s_c[1][0], c1g = s_c[1][1], c1b = s_c[1][2];
     auto label = [&](int i) {
         int r, g, b; px(i, &r, &g, &b);
-        const double d0 = (r - c0r) * (r - c0r) + (g - c0g) * (g - c0g) + (b - c0b) * (b - c0b);
-        const double d1 = (r - c1r) * (r - c1r) + (g - c1g) * (g - c1g) + (b - c1b) * (b - c1b);
-        return d1 < d0 ? 1 : 0;
+        return assign(r, g, b, s_c);
     };
     const int corner[4] = {label(0), label(w - 1), label((h - 1) * w), label(n - 1)};
     const int ones = corner[0] + corner[1] + corner[2] + corner[3];
-    const int background = ones > 2 ? 1 : (ones < 2 ? 0 : corner[0]);      // 2-2 tie: the cluster of the top-left corner (the reference's choice depends on sklearn's label numbering there)
+    const int background = ones > 2 ? 1 : 0;               // 2-2 tie: max(set(corners), key=corners.count) visits 0 first (proc.py:477-478; the label numbering is sklearn's: cluster 0 grew from the first seed)
     if (tid < 12) s_cnt[tid] = 0;
     __syncthreads();
     int cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -1,7 +1,8 @@
 """ORACLE — test infrastructure only (see eo_prims.c header).
 
 Team colours: ``Processor.get_team_mapping`` / ``detect_color`` of the reference's post-processor (eagle/processor.py:405-503,
-colour table :10-23).  K-means is scikit-learn's own ``KMeans(n_clusters=2, random_state=0)`` (the reference's call, sklearn is in this
+colour table :10-23).  K-means: ``kmeans2_labels`` restates scikit-learn 1.7's ``KMeans(n_clusters=2, random_state=0).fit(X).labels_`` (the
+reference's call) step by step and is pinned to sklearn's own labels (tests/test_oracle_colors.py, several hundred crops; sklearn is in this
 image); cv2's 8-bit BGR2HSV is eo_flow.c's restatement; inRange / bitwise_and / countNonZero are their numpy definitions.
 Pinned to the reference's own functions by tests/golden/team_golden.json (tests/golden/make_golden.py::dump_team runs proc.py itself
 over these primitives)."""
@@ -30,12 +31,56 @@ def color_counts(hsv, mask):
     return cnt
 
 
+# RandomState(0) is created anew by every KMeans(random_state=0).fit: its first three doubles are constants
+_U0, _U1, _U2 = 0.5488135039273248, 0.7151893663724195, 0.6027633760716439
+
+
+def kmeans2_labels(X):
+    """sklearn.cluster.KMeans(n_clusters=2, random_state=0).fit(X).labels_ for integer pixels X [n,3] (sklearn 1.7: n_init = 1,
+    k-means++ seeding, Lloyd, tol = 1e-4, max_iter = 300), restated:
+      * seeding (_kmeans_plusplus): centre 0 = X[choice(n)] = X[floor(u0 n)]; two candidates (n_local_trials = 2 + int(log 2)) at
+        searchsorted(cumsum(d0), (u1, u2) * sum(d0)) with d0 the squared distances to centre 0; the candidate with the smaller potential
+        sum(min(d0, d_candidate)) becomes centre 1.  Squared distances between pixels are exact integers;
+      * Lloyd (_kmeans_single_lloyd, float64): label = argmin_k |c_k|^2 - 2 x.c_k (ties to cluster 0), centres = cluster means; stop when the
+        labels repeat, or when the summed squared centre shift is <= mean(var(X, axis=0)) * 1e-4; the returned labels are the assignment to the
+        final centres.  Label 0 is the cluster that grew from centre 0."""
+    X = np.asarray(X).astype(np.int64)
+    n = len(X)
+    i0 = min(int(np.floor(_U0 * n)), n - 1)
+    d0 = ((X - X[i0]) ** 2).sum(1)
+    pot = int(d0.sum())
+    cum = np.cumsum(d0)
+    cands = [min(int(np.searchsorted(cum, u * pot, side="left")), n - 1) for u in (_U1, _U2)]
+    pots = [int(np.minimum(d0, ((X - X[c]) ** 2).sum(1)).sum()) for c in cands]
+    C = np.stack([X[i0], X[cands[int(np.argmin(pots))]]]).astype(np.float64)
+    Xf = X.astype(np.float64)
+    mean = Xf.sum(0) / n
+    tol = float(((Xf ** 2).sum(0) / n - mean * mean).sum() / 3.0 * 1e-4)
+    labels, strict = None, False
+    for _ in range(300):
+        new = np.argmin((C ** 2).sum(1)[None, :] - 2.0 * (Xf[:, :1] * C[None, :, 0] + Xf[:, 1:2] * C[None, :, 1] + Xf[:, 2:3] * C[None, :, 2]), 1)
+        Cn = C.copy()
+        for k in range(2):
+            m = new == k
+            if m.any():
+                Cn[k] = Xf[m].sum(0) / m.sum()
+        same = labels is not None and np.array_equal(new, labels)
+        shift = float(((Cn - C) ** 2).sum())
+        labels, C = new, Cn
+        if same:
+            strict = True
+            break
+        if shift <= tol:
+            break
+    if not strict:
+        labels = np.argmin((C ** 2).sum(1)[None, :] - 2.0 * (Xf[:, :1] * C[None, :, 0] + Xf[:, 1:2] * C[None, :, 1] + Xf[:, 2:3] * C[None, :, 2]), 1)
+    return labels
+
+
 def detect_color(image, labels=None):
     """proc.py:466-503 -> [(colour, count)] sorted by count, descending (stable).  labels: optional precomputed 2-means labels."""
     if labels is None:
-        from sklearn.cluster import KMeans
-        rgb = image[..., ::-1]
-        labels = KMeans(n_clusters=2, random_state=0).fit(rgb.reshape(-1, 3)).labels_
+        labels = kmeans2_labels(image[..., ::-1].reshape(-1, 3))
     labels = np.asarray(labels).reshape(image.shape[:2])
     corners = [labels[0, 0], labels[0, -1], labels[-1, 0], labels[-1, -1]]
     non_player = max(set(corners), key=corners.count)

@@ -140,50 +140,45 @@ template <> struct Vec<float> {
 // K4: y = relu(((base + up(z0)) + up(z1)) + up(z2)), bilinear align_corners=True
 //     (F.interpolate + sum + ReLU, eagle/models/keypoint_hrnet.py:290-309)
 // ------------------------------------------------------------------------------------------------------------
-struct FuseArgs { TView base, y; TView z[3]; int n_up; int relu; };
+struct FuseArgs { TView base, y; TView z[3]; float sh[3], sw[3]; int n_up; int relu; };     // sh / sw: (z.h - 1) / (H - 1), (z.w - 1) / (W - 1) (fp32 division, done once on the host)
 
+// One workgroup = 256 (column, channel-group) items of ONE output row (grid.x = frame * H + row): the row decomposition is scalar, one
+// integer division per thread remains, and the scale factors arrive as arguments — the kernel is bound by its VALU instruction count
+// (one 16-byte output costs several hundred of them), not by HBM, so these are what its time is made of.
 template <typename T>
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
 {
     constexpr int VN = Vec<T>::N;
     const int H = a.y.h, W = a.y.w, groups = a.y.c / VN;
-    // 32-bit index arithmetic (the launcher checks that every tensor has fewer than 2^31 elements): the four divisions per item
-    // are a visible share of this kernel's instruction count in 64 bits
-    const unsigned total = (unsigned)a.y.n * H * W * groups;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int g = (int)(i % (unsigned)groups);
-        const unsigned pix = i / (unsigned)groups;
-        const int ox = (int)(pix % (unsigned)W);
-        const unsigned rowi = pix / (unsigned)W;
-        const int oy = (int)(rowi % (unsigned)H);
-        const int n = (int)(rowi / (unsigned)H);
-        Vec<T> acc; acc.load(a.base.p, (size_t)pix * a.base.cs + a.base.off + g * VN);
-        for (int j = 0; j < a.n_up; ++j) {
-            const TView& z = a.z[j];
-            const float sh = (H > 1) ? (float)(z.h - 1) / (float)(H - 1) : 0.f;
-            const float sw = (W > 1) ? (float)(z.w - 1) / (float)(W - 1) : 0.f;
-            const float fy = sh * (float)oy, fx = sw * (float)ox;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < z.h - 1 ? 1 : 0), x1 = x0 + (x0 < z.w - 1 ? 1 : 0);
-            const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
-            const unsigned b = (unsigned)n * z.h * z.w, co = (unsigned)(z.off + g * VN);
-            Vec<T> p00, p01, p10, p11;
-            p00.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x0) * (unsigned)z.cs + co));
-            p01.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x1) * (unsigned)z.cs + co));
-            p10.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x0) * (unsigned)z.cs + co));
-            p11.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x1) * (unsigned)z.cs + co));
+    const unsigned col = blockIdx.y * 256u + threadIdx.x;
+    if (col >= (unsigned)(W * groups)) return;
+    const int row = blockIdx.x, n = row / H, oy = row - n * H;
+    const int ox = (int)(col / (unsigned)groups), g = (int)(col - (unsigned)ox * (unsigned)groups);
+    const unsigned pix = (unsigned)row * (unsigned)W + (unsigned)ox;
+    Vec<T> acc; acc.load(a.base.p, (size_t)pix * a.base.cs + a.base.off + g * VN);
+    for (int j = 0; j < a.n_up; ++j) {
+        const TView& z = a.z[j];
+        const float fy = a.sh[j] * (float)oy, fx = a.sw[j] * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < z.h - 1 ? 1 : 0), x1 = x0 + (x0 < z.w - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+        const unsigned b = (unsigned)n * z.h * z.w, co = (unsigned)(z.off + g * VN);
+        Vec<T> p00, p01, p10, p11;
+        p00.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x0) * (unsigned)z.cs + co));
+        p01.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x1) * (unsigned)z.cs + co));
+        p10.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x0) * (unsigned)z.cs + co));
+        p11.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x1) * (unsigned)z.cs + co));
 #pragma unroll
-            for (int k = 0; k < VN; ++k) {
-                const float top = fmaf(lx1, p01.v[k], lx0 * p00.v[k]);
-                const float bot = fmaf(lx1, p11.v[k], lx0 * p10.v[k]);
-                acc.v[k] = acc.v[k] + fmaf(ly1, bot, ly0 * top);
-            }
+        for (int k = 0; k < VN; ++k) {
+            const float top = fmaf(lx1, p01.v[k], lx0 * p00.v[k]);
+            const float bot = fmaf(lx1, p11.v[k], lx0 * p10.v[k]);
+            acc.v[k] = acc.v[k] + fmaf(ly1, bot, ly0 * top);
         }
-        if (a.relu)
-#pragma unroll
-            for (int k = 0; k < VN; ++k) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : 0.f;
-        acc.store(a.y.p, (size_t)pix * a.y.cs + a.y.off + g * VN);
     }
+    if (a.relu)
+#pragma unroll
+        for (int k = 0; k < VN; ++k) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : 0.f;
+    acc.store(a.y.p, (size_t)pix * a.y.cs + a.y.off + g * VN);
 }
 
 static int ew_blocks(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 256 * 16); }
@@ -191,14 +186,20 @@ static int ew_blocks(size_t total) { return (int)std::min<size_t>((total + 255) 
 void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s)
 {
     FuseArgs a; a.base = base; a.y = y; a.n_up = n_up; a.relu = relu;
-    for (int i = 0; i < n_up; ++i) a.z[i] = ups[i].z;
+    for (int i = 0; i < n_up; ++i) {
+        a.z[i] = ups[i].z;
+        a.sh[i] = (y.h > 1) ? (float)(ups[i].z.h - 1) / (float)(y.h - 1) : 0.f;
+        a.sw[i] = (y.w > 1) ? (float)(ups[i].z.w - 1) / (float)(y.w - 1) : 0.f;
+    }
     const int vn = y.f32 ? 4 : 8;
     const size_t total = (size_t)y.n * y.h * y.w * (y.c / vn);
     size_t biggest = (size_t)y.n * y.h * y.w * std::max(y.cs, base.cs);
     for (int i = 0; i < n_up; ++i) biggest = std::max(biggest, (size_t)ups[i].z.n * ups[i].z.h * ups[i].z.w * ups[i].z.cs);
     if (biggest >= ((size_t)1 << 31)) fail(EAGLE_E_INVALID, "fuse: a tensor of %d frames reaches 2^31 elements; use a smaller device batch", y.n);
-    if (y.f32) hipLaunchKernelGGL(fuse_sum_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fuse_sum_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, a);
+    (void)total;
+    const dim3 grid((unsigned)(y.n * y.h), (unsigned)((y.w * (y.c / vn) + 255) / 256));
+    if (y.f32) hipLaunchKernelGGL(fuse_sum_kernel<float>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(fuse_sum_kernel<_Float16>, grid, dim3(256), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -145,34 +145,47 @@ struct FuseArgs { TView base, y; TView z[3]; float sh[3], sw[3]; int n_up; int r
 // One workgroup = 256 (column, channel-group) items of ONE output row (grid.x = frame * H + row): the row decomposition is scalar, one
 // integer division per thread remains, and the scale factors arrive as arguments — the kernel is bound by its VALU instruction count
 // (one 16-byte output costs several hundred of them), not by HBM, so these are what its time is made of.
-template <typename T>
+template <typename T, int NUP>
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
 {
     constexpr int VN = Vec<T>::N;
     const int H = a.y.h, W = a.y.w, groups = a.y.c / VN;
     const unsigned col = blockIdx.y * 256u + threadIdx.x;
     if (col >= (unsigned)(W * groups)) return;
-    const int row = blockIdx.x, n = row / H, oy = row - n * H;
+    // XCD-aware row order: workgroup b runs on XCD b % 8, so XCD x takes the contiguous band of rows [x * band, (x + 1) * band): the low-resolution
+    // rows that 2 - 8 neighbouring output rows share are then fetched into ONE L2 instead of several (PMC: 1.9x read amplification without it)
+    const int band = gridDim.x >> 3, row = (int)(blockIdx.x & 7) * band + (int)(blockIdx.x >> 3);
+    if (row >= a.y.n * H) return;
+    const int n = row / H, oy = row - n * H;
     const int ox = (int)(col / (unsigned)groups), g = (int)(col - (unsigned)ox * (unsigned)groups);
     const unsigned pix = (unsigned)row * (unsigned)W + (unsigned)ox;
+    // all 1 + 4 * NUP loads are requested before the first use: one memory round trip per output instead of one per operand (the kernel was
+    // bound by that latency chain, not by bandwidth or instruction count)
     Vec<T> acc; acc.load(a.base.p, (size_t)pix * a.base.cs + a.base.off + g * VN);
-    for (int j = 0; j < a.n_up; ++j) {
+    constexpr int NU = NUP > 0 ? NUP : 1;
+    Vec<T> p00[NU], p01[NU], p10[NU], p11[NU];
+    float ly1[NU], lx1[NU];
+#pragma unroll
+    for (int j = 0; j < NUP; ++j) {
         const TView& z = a.z[j];
         const float fy = a.sh[j] * (float)oy, fx = a.sw[j] * (float)ox;
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + (y0 < z.h - 1 ? 1 : 0), x1 = x0 + (x0 < z.w - 1 ? 1 : 0);
-        const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+        ly1[j] = fy - (float)y0; lx1[j] = fx - (float)x0;
         const unsigned b = (unsigned)n * z.h * z.w, co = (unsigned)(z.off + g * VN);
-        Vec<T> p00, p01, p10, p11;
-        p00.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x0) * (unsigned)z.cs + co));
-        p01.load(z.p, (size_t)((b + (unsigned)y0 * z.w + x1) * (unsigned)z.cs + co));
-        p10.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x0) * (unsigned)z.cs + co));
-        p11.load(z.p, (size_t)((b + (unsigned)y1 * z.w + x1) * (unsigned)z.cs + co));
+        p00[j].load(z.p, (size_t)((b + (unsigned)y0 * z.w + x0) * (unsigned)z.cs + co));
+        p01[j].load(z.p, (size_t)((b + (unsigned)y0 * z.w + x1) * (unsigned)z.cs + co));
+        p10[j].load(z.p, (size_t)((b + (unsigned)y1 * z.w + x0) * (unsigned)z.cs + co));
+        p11[j].load(z.p, (size_t)((b + (unsigned)y1 * z.w + x1) * (unsigned)z.cs + co));
+    }
+#pragma unroll
+    for (int j = 0; j < NUP; ++j) {
+        const float ly0 = 1.0f - ly1[j], lx0 = 1.0f - lx1[j];
 #pragma unroll
         for (int k = 0; k < VN; ++k) {
-            const float top = fmaf(lx1, p01.v[k], lx0 * p00.v[k]);
-            const float bot = fmaf(lx1, p11.v[k], lx0 * p10.v[k]);
-            acc.v[k] = acc.v[k] + fmaf(ly1, bot, ly0 * top);
+            const float top = fmaf(lx1[j], p01[j].v[k], lx0 * p00[j].v[k]);
+            const float bot = fmaf(lx1[j], p11[j].v[k], lx0 * p10[j].v[k]);
+            acc.v[k] = acc.v[k] + fmaf(ly1[j], bot, ly0 * top);
         }
     }
     if (a.relu)
@@ -197,9 +210,17 @@ void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, c
     for (int i = 0; i < n_up; ++i) biggest = std::max(biggest, (size_t)ups[i].z.n * ups[i].z.h * ups[i].z.w * ups[i].z.cs);
     if (biggest >= ((size_t)1 << 31)) fail(EAGLE_E_INVALID, "fuse: a tensor of %d frames reaches 2^31 elements; use a smaller device batch", y.n);
     (void)total;
-    const dim3 grid((unsigned)(y.n * y.h), (unsigned)((y.w * (y.c / vn) + 255) / 256));
-    if (y.f32) hipLaunchKernelGGL(fuse_sum_kernel<float>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fuse_sum_kernel<_Float16>, grid, dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((y.n * y.h + 7) / 8 * 8), (unsigned)((y.w * (y.c / vn) + 255) / 256));
+#define FUSE_LAUNCH(T_) \
+    switch (n_up) { \
+    case 0: hipLaunchKernelGGL((fuse_sum_kernel<T_, 0>), grid, dim3(256), 0, s, a); break; \
+    case 1: hipLaunchKernelGGL((fuse_sum_kernel<T_, 1>), grid, dim3(256), 0, s, a); break; \
+    case 2: hipLaunchKernelGGL((fuse_sum_kernel<T_, 2>), grid, dim3(256), 0, s, a); break; \
+    default: hipLaunchKernelGGL((fuse_sum_kernel<T_, 3>), grid, dim3(256), 0, s, a); break; \
+    }
+    if (n_up > 3) fail(EAGLE_E_INVALID, "fuse: at most three low-resolution operands");
+    if (y.f32) { FUSE_LAUNCH(float) } else { FUSE_LAUNCH(_Float16) }
+#undef FUSE_LAUNCH
     HIP_CHECK(hipGetLastError());
 }
 

@@ -1,0 +1,38 @@
+// Shared between conv.hip and the A-direct translation units (conv_ad_s1.hip / conv_ad_s2.hip include conv_ad_kernel.inc): splitting the
+// instantiations over three files keeps a clean parallel build at about a third of the single-file compile time.
+#pragma once
+#include "common.h"
+
+namespace eagle {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half4 = __attribute__((ext_vector_type(4))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+
+struct ConvArgs {
+    const void* x; int xcs, xoff; int N, H, W;
+    const void* w; const float* bias;
+    void* y; int ycs, yoff; int Ho, Wo;
+    const void* r1; int r1cs, r1off;
+    const void* r2; int r2cs, r2off;
+    int pre_act, post_act, out_f32;
+    int wx, tiles_x, tiles_y, nchunks;
+    int gy;                 // number of Cout blocks
+    int xcd;                // 1: XCD-aware work order (1-D grid; each XCD owns a contiguous range of (tile, Cout-block) items)
+    ArgmaxPart* am;         // fused heat-map maxima (head convolution): partials [frame][tile][am_cs] instead of the output tensor
+    int am_cs;
+    const void* zeros;      // >= 16 zero bytes in global memory (source of out-of-image pixels for unconditional loads / LDS-DMA)
+    void* trash;            // >= 4 KiB of scratch global memory (target of out-of-image results for unconditional stores)
+};
+
+typedef void (*ConvKernel)(ConvArgs);
+struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
+const Inst* conv_inst_part(int part, int* n);       // instance tables of conv_inst_0..3.hip (declared per part below)
+const Inst* conv_inst_part0(int* n); const Inst* conv_inst_part1(int* n); const Inst* conv_inst_part2(int* n); const Inst* conv_inst_part3(int* n);
+// the A-direct kernel instance for (cout_groups x pixel_groups, number of residual operands): wide = 4 x 1 (BN 192), otherwise 2 x 2 (BN 96)
+ConvKernel conv_ad_kernel_s1(bool wide, int n_res);
+ConvKernel conv_ad_kernel_s2(bool wide, int n_res);
+
+}  // namespace eagle

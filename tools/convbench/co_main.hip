@@ -8,6 +8,14 @@
 #include <cmath>
 #include <vector>
 #include CONV_SRC
+#ifndef CONV_SINGLE_FILE      // the library keeps its kernel instances in separate translation units (build time); a tool is one file
+#include "../../eagle_amd/csrc/conv_inst_0.hip"
+#include "../../eagle_amd/csrc/conv_inst_1.hip"
+#include "../../eagle_amd/csrc/conv_inst_2.hip"
+#include "../../eagle_amd/csrc/conv_inst_3.hip"
+#include "../../eagle_amd/csrc/conv_ad_s1.hip"
+#include "../../eagle_amd/csrc/conv_ad_s2.hip"
+#endif
 namespace eagle {
 void ensure_max_dynamic_lds(const void* fn, int bytes) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
 void fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); exit(1); }

@@ -266,7 +266,7 @@ def main():
         tj = json.load(open(tf))
         if tj.get("batch") == B and tj.get("detector") == a.detector and tj.get("precision") == a.precision:
             traffic = tj["conv_family"]["hbm_bytes_per_launch"]
-            traffic_src = f"NOT measured in this run: read from profiles/conv_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build {tj.get('build', '?')})"
+            traffic_src = f"NOT measured in this run: read from profiles/conv_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build {tj.get('build', '?')}; the library's streams run concurrently in those passes, so kernels of other streams that overlap a convolution are counted into it: an upper bound)"
     res = None
     if rank == 0:
         res = {

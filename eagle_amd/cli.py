@@ -46,7 +46,8 @@ def main(argv=None):
     ap.add_argument("--num-keypoint-detection", type=int, default=3, help="key-point model runs per second (main.py:27: 3)")
     ap.add_argument("--every-frame", action="store_true", help="key-points and homography on every frame (stateless configuration)")
     ap.add_argument("--calibration", action="store_true")
-    ap.add_argument("--tracker", action="store_true", help="key players by track id (BoT-SORT association, ReID / camera-motion compensation off) instead of the detection index")
+    ap.add_argument("--tracker", action="store_true", help="key players by track id (BoT-SORT association, ReID off) instead of the detection index")
+    ap.add_argument("--camera-motion", action="store_true", help="with --tracker: compensate camera motion (warp from sparse LK on a grid; boxmot uses ECC)")
     ap.add_argument("--keypoint-weights", help="HRNet state-dict (.pth as the reference loads at cm.py:58-59: keys unnormalized_model.0.* / unnormalized_model.1.*)")
     ap.add_argument("--detector-weights", help="detector checkpoint: a torch state-dict (.pth) with ultralytics key names model.N.*, or an ultralytics .pt whose 'model' entry has .state_dict()")
     ap.add_argument("--synthetic-weights", action="store_true", help="run with seeded RANDOM networks (plumbing / benchmarking only: the coordinates are meaningless)")
@@ -72,7 +73,7 @@ def main(argv=None):
         print("WARNING: running with seeded RANDOM network weights: the output has the reference's schema but no meaning", flush=True)
     model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
                             precision=a.precision, device=a.device, seed=a.seed,
-                            hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker)
+                            hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker, camera_motion=a.camera_motion)
     t0 = time.perf_counter()
     nh, nk = (a.fps, a.fps) if a.every_frame else (a.num_homography, a.num_keypoint_detection)
     coordinates = model.get_coordinates(frames, a.fps, num_homography=nh, num_keypoint_detection=nk, verbose=False, calibration=a.calibration)

@@ -3,18 +3,18 @@ keypoint_interval > 1 and/or calibration) over the clip session of the C ABI (in
 
 What runs where: the gray pyramids of all frames; per chunk of frames the detector on every frame and HRNet on every
 keypoint_interval-th frame, in batches, on two streams; and on a third stream ONE pyramidal-LK launch and ONE loop-body launch per
-frame, stream-ordered, without host round trips.  (The library currently makes the network passes of chunk c+1 wait for the loop
-of chunk c: overlapped, the loop's LK results were not reproducible — DESIGN.md §8c, open issue.)  The host steps in only where the reference itself leaves its cadence: the first-frame search (cm.py:289-311) and on-demand detections
+frame, stream-ordered, without host round trips; the network passes of chunk c+1 run under the loop of chunk c.  The host steps in only where the reference itself leaves its cadence: the first-frame search (cm.py:289-311) and on-demand detections
 (cm.py:317), after which the loop resumes at the frame that asked."""
 import numpy as np
 
 from . import lib
 
 
-def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None):
+def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None, motion=None):
     """h: lib.Handle; dptr: n BGR frames resident in HBM.  -> RESULT_DTYPE[n].
     keypoint_source(i) -> FLOWKP_DTYPE array: an external key-point detector replacing HRNet (what detect_keypoints(frames[i])
-    would return, in dict order); the parity tests use it to replay the reference's canned detections."""
+    would return, in dict order); the parity tests use it to replay the reference's canned detections.
+    motion: a list that receives the [n, 6] camera motions of the clip (eagle_clip_motion) while the session is open (tracker CMC)."""
     detected = []
 
     def detect(first, stride=1, count=1):
@@ -45,6 +45,8 @@ def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=Fal
             detect(stalled)                                                                          # cm.py:317 on-demand detection
             stalled = h.clip_run(stalled, n, keypoint_interval, homography_interval, calibration, wait=True)
         recs = h.clip_fetch(n)
+        if motion is not None:
+            motion.append(h.clip_motion(0, n))
     finally:
         h.clip_close()
     if stats is not None:

@@ -7,7 +7,8 @@ Same constructor keywords and method names as the reference: ``CoordinateModel(k
 the reference (optical-flow propagation between detections, first-frame search, on-demand detection, calibration:
 cm.py:188-416).  ``tracker=True`` keys Player / Goalkeeper entries by track id like the reference does through boxmot's BotSort
 (cm.py:574-596): the library's BoT-SORT motion / IoU association with ReID and camera-motion compensation off (include/eagle.h,
-eagle_track_*; stated deviations).  ``tracker=False`` (default) is the reference's detection-index fallback (cm.py:598-627), the
+eagle_track_*; stated deviations); ``camera_motion=True`` adds BoT-SORT's camera-motion compensation, the warp estimated from sparse LK on a
+grid (eagle_clip_motion) instead of boxmot's ECC.  ``tracker=False`` (default) is the reference's detection-index fallback (cm.py:598-627), the
 stateless configuration of SURVEY §8a."""
 import numpy as np
 
@@ -18,9 +19,10 @@ from .pitch import INTERSECTION_TO_PITCH_POINTS
 class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
                  detector="n", det_imgsz=640, batch=8, precision="f16", device=0, hrnet_state_dict=None,
-                 detector_state_dict=None, seed=0, use_graph=False, tracker=False):
+                 detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
+        self.camera_motion = camera_motion
         self.batch = batch
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
                                  det_imgsz=det_imgsz, batch=batch,
@@ -42,13 +44,14 @@ class CoordinateModel:
         homography_interval = max(1, int(fps / max(1, num_homography)))
         keypoint_interval = max(1, int(fps / max(1, num_keypoint_detection)))
         if calibration or keypoint_interval != 1:
-            recs = self.flow_records(frames, keypoint_interval, homography_interval, calibration)
+            motion = [] if (self.tracker and self.camera_motion) else None
+            recs = self.flow_records(frames, keypoint_interval, homography_interval, calibration, motion=motion)
             if self.tracker:
-                self._track(recs)
+                self._track(recs, motion[0] if motion else None)
             return {i: records.to_reference_dict(r, i, fps, own_h=bool(r["pad"][0])) for i, r in enumerate(recs)}
         recs = self.process_records(frames)
         if self.tracker:
-            self._track(recs)
+            self._track(recs, self._clip_motion(frames) if self.camera_motion else None)
         own = np.ones(len(recs), bool)
         if homography_interval > 1:
             # cm.py:333-367: H is solved on scheduled frames or while the retry flag is set, and carried otherwise.  Every
@@ -71,20 +74,33 @@ class CoordinateModel:
                 recs = self.handle.reproject(np.ascontiguousarray(recs), Hs, flags)
         return {i: records.to_reference_dict(r, i, fps, own_h=bool(own[i])) for i, r in enumerate(recs)}
 
-    def _track(self, recs):
+    def _track(self, recs, warps=None):
         """One clip: track ids + smoothed boxes into the records (frame order), pitch coordinates re-projected on the GPU."""
         self.handle.track_open()
-        self.handle.track_frames(recs)
+        self.handle.track_frames(recs, warps)
         return recs
 
-    def flow_records(self, frames, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None):
+    def _clip_motion(self, frames):
+        """[n, 6] camera motions of a clip that is not in a clip session yet: gray pyramids + sparse LK on the GPU (eagle_clip_open / _motion)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        d = self.handle.upload(frames)
+        try:
+            self.handle.clip_open(d, len(frames))
+            try:
+                return self.handle.clip_motion(0, len(frames))
+            finally:
+                self.handle.clip_close()
+        finally:
+            self.handle.free(d)
+
+    def flow_records(self, frames, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None, motion=None):
         """Records of the reference loop in a stateful cadence (cm.py:188-416); see eagle_amd/clip.py."""
         frames = np.ascontiguousarray(frames, np.uint8)
         if len(frames) == 0:
             return np.zeros(0, lib.RESULT_DTYPE)
         d = self.handle.upload(frames)
         try:
-            return clip.run_clip(self.handle, d, len(frames), keypoint_interval, homography_interval, calibration, stats, keypoint_source)
+            return clip.run_clip(self.handle, d, len(frames), keypoint_interval, homography_interval, calibration, stats, keypoint_source, motion)
         finally:
             self.handle.free(d)
 

@@ -149,7 +149,8 @@ void team_colors_launch(const uint8_t* d_bgr, int n_frames, int fh, int fw, cons
 struct Tracker;
 Tracker* tracker_create(const EagleTrackParams* p);
 void tracker_destroy(Tracker* t);
-bool tracker_apply(Tracker* t, EagleFrameResult* rec, int frame_h, int frame_w, double detector_conf);   // true: the record's persons are now keyed by track id
+bool tracker_apply(Tracker* t, EagleFrameResult* rec, int frame_h, int frame_w, double detector_conf, const double* warp = nullptr);   // true: the record's persons are now keyed by track id; warp: 2 x 3 camera motion previous frame -> this one
+void similarity_ransac(const double* p0, const double* p1, int n, double* W6);       // camera motion from matched points (tracker.hip)
 int lk_debug(const char* key, long long value, void* out, long long out_bytes);   // developer diagnostics behind eagle_debug
 // heat-map maxima of `n` frames -> mem[first + k*stride] (threshold / pixel mapping / dedup, cm.py:231-251, 500-518)
 void decode_mem_launch(const ArgmaxPart* parts, int n, const PostParams& pp, MemList* mem, int first, int stride, hipStream_t s);

@@ -1138,7 +1138,9 @@ int eagle_track_open(EagleHandle* h, const EagleTrackParams* params)
     API_END(h)
 }
 
-int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n)
+int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n) { return eagle_track_frames_cmc(h, recs, n, nullptr); }
+
+int eagle_track_frames_cmc(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps)
 {
     if (!h) return EAGLE_E_INVALID;
     API_BEGIN
@@ -1149,7 +1151,7 @@ int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n)
     std::vector<uint8_t> flags((size_t)n, 0);
     bool any = false;
     for (int i = 0; i < n; ++i) {
-        if (!eagle::tracker_apply(h->tracker, recs + i, h->cfg.frame_h, h->cfg.frame_w, h->cfg.detector_conf)) continue;
+        if (!eagle::tracker_apply(h->tracker, recs + i, h->cfg.frame_h, h->cfg.frame_w, h->cfg.detector_conf, warps ? warps + (size_t)i * 6 : nullptr)) continue;
         any = true;
         flags[i] = recs[i].H_valid ? 1 : 2;                  // re-project the moved foot points with the frame's own homography
         memcpy(&Hs[(size_t)i * 9], recs[i].H, sizeof(double) * 9);
@@ -1254,6 +1256,39 @@ int eagle_clip_flow(EagleHandle* h, int src_frame, int dst_frame, int hue_frame,
     for (int k = 0; k < z.flow_n; ++k) out[k] = z.flow[k];
     if (next_pts) memcpy(next_pts, z.lk_next, sizeof(float) * 2 * n_in);
     if (status) memcpy(status, z.lk_status, n_in);
+    API_END(h)
+}
+
+int eagle_clip_motion(EagleHandle* h, int first, int count, double* warps)
+{
+    CLIP_CHECK(h, h->clip.open && first >= 0 && count >= 0 && first + count <= h->clip.cv.n && (warps || count == 0), "eagle_clip_motion: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    EagleHandle::Clip& c = h->clip;
+    constexpr int GW = 8, GH = 6, NP = GW * GH;              // 48 grid points: one launch of the key-point LK kernel (<= EAGLE_N_LANDMARKS)
+    ChainState& z = *c.h_st;
+    for (int i = 0; i < count; ++i) {
+        double* W = warps + (size_t)i * 6;
+        W[0] = 1; W[1] = 0; W[2] = 0; W[3] = 0; W[4] = 1; W[5] = 0;
+        const int f = first + i;
+        if (f == 0) continue;
+        memset(&z, 0, sizeof(z));
+        z.stalled = -1; z.n_prev = NP;
+        for (int gy = 0; gy < GH; ++gy)
+            for (int gx = 0; gx < GW; ++gx) {
+                EagleFlowKp& k = z.prev[gy * GW + gx];
+                k.label = gy * GW + gx; k.score = 1.f;
+                k.x = (int)floor((gx + 0.5) * h->cfg.frame_w / GW); k.y = (int)floor((gy + 0.5) * h->cfg.frame_h / GH);
+            }
+        HIP_CHECK(hipMemcpyAsync(c.st_op, &z, sizeof(z), hipMemcpyHostToDevice, h->s_main));
+        lk_launch(c.cv, f - 1, f, c.st_op, nullptr, 1, h->s_main);
+        HIP_CHECK(hipMemcpyAsync(&z, c.st_op, sizeof(z), hipMemcpyDeviceToHost, h->s_main));
+        HIP_CHECK(hipStreamSynchronize(h->s_main));
+        double p0[2 * NP], p1[2 * NP]; int m = 0;
+        for (int k = 0; k < NP; ++k)
+            if (z.lk_status[k] == 1) { p0[2 * m] = z.prev[k].x; p0[2 * m + 1] = z.prev[k].y; p1[2 * m] = z.lk_next[2 * k]; p1[2 * m + 1] = z.lk_next[2 * k + 1]; ++m; }
+        eagle::similarity_ransac(p0, p1, m, W);
+    }
     API_END(h)
 }
 

@@ -157,6 +157,75 @@ void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thr
 bool contains(const std::vector<TP>& v, const TP& t) { return std::find(v.begin(), v.end(), t) != v.end(); }
 }  // namespace
 
+// BoT-SORT's STrack.multi_gmc for one track: R8 = kron(I4, R) on the 8-state (it rotates (w, h) and the velocity pairs too), t added to (cx, cy)
+static void apply_warp(Track& t, const double* w)
+{
+    const double r00 = w[0], r01 = w[1], tx = w[2], r10 = w[3], r11 = w[4], ty = w[5];
+    double m[8];
+    for (int k = 0; k < 4; ++k) { m[2 * k] = r00 * t.mean[2 * k] + r01 * t.mean[2 * k + 1]; m[2 * k + 1] = r10 * t.mean[2 * k] + r11 * t.mean[2 * k + 1]; }
+    m[0] += tx; m[1] += ty;
+    for (int i = 0; i < 8; ++i) t.mean[i] = m[i];
+    double a[8][8], c[8][8];                             // a = R8 * cov, c = a * R8^T
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 8; ++j) {
+            a[2 * k][j] = r00 * t.cov[2 * k][j] + r01 * t.cov[2 * k + 1][j];
+            a[2 * k + 1][j] = r10 * t.cov[2 * k][j] + r11 * t.cov[2 * k + 1][j];
+        }
+    for (int i = 0; i < 8; ++i)
+        for (int k = 0; k < 4; ++k) {
+            c[i][2 * k] = a[i][2 * k] * r00 + a[i][2 * k + 1] * r01;
+            c[i][2 * k + 1] = a[i][2 * k] * r10 + a[i][2 * k + 1] * r11;
+        }
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) t.cov[i][j] = c[i][j];
+}
+
+// Camera motion from matched points (oracle/tracker.py::similarity_ransac, operation by operation): 200 two-point similarity hypotheses drawn
+// by a fixed LCG, most residuals < 3 px wins (first on ties), least squares on the consensus set.  W: [[a, -b, tx], [b, a, ty]] row-major.
+void similarity_ransac(const double* p0, const double* p1, int n, double* W)
+{
+    W[0] = 1; W[1] = 0; W[2] = 0; W[3] = 0; W[4] = 1; W[5] = 0;
+    if (n < 2) return;
+    const double thr2 = 3.0 * 3.0;
+    unsigned long long state = 12345;
+    int best_cnt = -1; double ba = 0, bb = 0, btx = 0, bty = 0; bool have = false;
+    for (int it = 0; it < 200; ++it) {
+        state = (state * 1103515245ull + 12345ull) & 0x7FFFFFFFull; const int i = (int)((state >> 8) % (unsigned long long)n);
+        state = (state * 1103515245ull + 12345ull) & 0x7FFFFFFFull; const int j = (int)((state >> 8) % (unsigned long long)n);
+        if (i == j) continue;
+        const double dx0 = p0[2 * j] - p0[2 * i], dy0 = p0[2 * j + 1] - p0[2 * i + 1];
+        const double dx1 = p1[2 * j] - p1[2 * i], dy1 = p1[2 * j + 1] - p1[2 * i + 1];
+        const double den = dx0 * dx0 + dy0 * dy0;
+        if (den < 1e-9) continue;
+        const double a = (dx0 * dx1 + dy0 * dy1) / den, b = (dx0 * dy1 - dy0 * dx1) / den;
+        const double tx = p1[2 * i] - (a * p0[2 * i] - b * p0[2 * i + 1]), ty = p1[2 * i + 1] - (b * p0[2 * i] + a * p0[2 * i + 1]);
+        int cnt = 0;
+        for (int k = 0; k < n; ++k) {
+            const double ex = a * p0[2 * k] - b * p0[2 * k + 1] + tx - p1[2 * k], ey = b * p0[2 * k] + a * p0[2 * k + 1] + ty - p1[2 * k + 1];
+            cnt += (ex * ex + ey * ey) < thr2;
+        }
+        if (cnt > best_cnt) { best_cnt = cnt; ba = a; bb = b; btx = tx; bty = ty; have = true; }
+    }
+    if (!have) return;
+    std::vector<int> idx;
+    for (int k = 0; k < n; ++k) {
+        const double ex = ba * p0[2 * k] - bb * p0[2 * k + 1] + btx - p1[2 * k], ey = bb * p0[2 * k] + ba * p0[2 * k + 1] + bty - p1[2 * k + 1];
+        if (ex * ex + ey * ey < thr2) idx.push_back(k);
+    }
+    if (idx.size() < 2) return;
+    const double m = (double)idx.size();
+    double c0x = 0, c0y = 0, c1x = 0, c1y = 0;
+    for (int k : idx) { c0x += p0[2 * k]; c0y += p0[2 * k + 1]; c1x += p1[2 * k]; c1y += p1[2 * k + 1]; }
+    c0x /= m; c0y /= m; c1x /= m; c1y /= m;
+    double sxx = 0, sdot = 0, scross = 0;
+    for (int k : idx) {
+        const double qx = p0[2 * k] - c0x, qy = p0[2 * k + 1] - c0y, rx = p1[2 * k] - c1x, ry = p1[2 * k + 1] - c1y;
+        sxx += qx * qx + qy * qy; sdot += qx * rx + qy * ry; scross += qx * ry - qy * rx;
+    }
+    if (sxx < 1e-9) return;
+    const double a = sdot / sxx, b = scross / sxx;
+    W[0] = a; W[1] = -b; W[2] = c1x - (a * c0x - b * c0y); W[3] = b; W[4] = a; W[5] = c1y - (b * c0x + a * c0y);
+}
+
 struct Tracker {
     double hi = 0.5, lo = 0.1, newt = 0.6, match = 0.8;
     int max_time_lost = 30;
@@ -170,7 +239,8 @@ struct Tracker {
         t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
     }
     // dets: x1,y1,x2,y2,conf,cls rows -> the activated tracked tracks
-    void update(const EagleDet* dets, int n, std::vector<TP>& out)
+    // warp: optional 2 x 3 camera motion of the previous frame -> this one, applied after the prediction like BoT-SORT's multi_gmc
+    void update(const EagleDet* dets, int n, std::vector<TP>& out, const double* warp = nullptr)
     {
         ++frame_id;
         std::vector<TP> first, second;
@@ -192,6 +262,7 @@ struct Tracker {
             if (t->state != T_TRACKED) { t->mean[6] = 0; t->mean[7] = 0; }
             kf_predict(*t);
         }
+        if (warp) { for (auto& t : pool) apply_warp(*t, warp); for (auto& t : unconfirmed) apply_warp(*t, warp); }
         std::vector<TP> activated, refind, lost_now, removed_now;
         std::vector<std::pair<int, int>> m; std::vector<int> ur, uc;
         assign(pool, first, match, m, ur, uc);
@@ -266,11 +337,11 @@ void tracker_destroy(Tracker* t) { delete t; }
 
 // cm.py:577-616 on one record: track rows -> Player / Goalkeeper entries keyed by track id (smoothed boxes); when the tracker reports
 // no player at all the reference falls back to the raw detections keyed by detection index — which is what the record already holds.
-bool tracker_apply(Tracker* T, EagleFrameResult* R, int frame_h, int frame_w, double detector_conf)
+bool tracker_apply(Tracker* T, EagleFrameResult* R, int frame_h, int frame_w, double detector_conf, const double* warp)
 {
     std::vector<TP> out;
     const int n = std::max(0, std::min(R->n_det, EAGLE_MAX_DET));
-    T->update(R->det, n, out);
+    T->update(R->det, n, out, warp);
     int persons = 0;
     for (auto& t : out) persons += (t->cls == 0 || t->cls == 1) && !((double)t->conf < detector_conf);
     if (persons == 0) return false;

@@ -109,6 +109,8 @@ def load():
     L.eagle_team_colors.argtypes = [vp, vp, i32, vp, i32, vp]
     L.eagle_track_open.argtypes = [vp, C.POINTER(EagleTrackParams)]
     L.eagle_track_frames.argtypes = [vp, vp, i32]
+    L.eagle_track_frames_cmc.argtypes = [vp, vp, i32, C.POINTER(C.c_double)]
+    L.eagle_clip_motion.argtypes = [vp, i32, i32, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -118,7 +120,7 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
-           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_team_colors"]
+           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_track_frames_cmc", "eagle_clip_motion", "eagle_team_colors"]
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
 E_REFERENCE_RAISES = -7
@@ -306,11 +308,21 @@ class Handle:
             p = C.byref(EagleTrackParams(**d))
         self._check(self.L.eagle_track_open(self._h, p), "track_open")
 
-    def track_frames(self, recs):
-        """In place: the next records of the clip being tracked (frame order)."""
+    def track_frames(self, recs, warps=None):
+        """In place: the next records of the clip being tracked (frame order).  warps: optional [len(recs), 6] camera motions (clip_motion)."""
         assert recs.dtype == RESULT_DTYPE and recs.flags.c_contiguous
-        self._check(self.L.eagle_track_frames(self._h, recs.ctypes.data_as(C.c_void_p), len(recs)), "track_frames")
+        w = None
+        if warps is not None:
+            w = np.ascontiguousarray(warps, np.float64).reshape(len(recs), 6)
+        self._check(self.L.eagle_track_frames_cmc(self._h, recs.ctypes.data_as(C.c_void_p), len(recs),
+                                                  w.ctypes.data_as(C.POINTER(C.c_double)) if w is not None else None), "track_frames")
         return recs
+
+    def clip_motion(self, first, count):
+        """[count, 6] float64: row-major 2 x 3 camera motion of frame first+i-1 -> first+i of the open clip session (identity for frame 0)."""
+        w = np.zeros((max(count, 0), 6), np.float64)
+        self._check(self.L.eagle_clip_motion(self._h, first, count, w.ctypes.data_as(C.POINTER(C.c_double))), "clip_motion")
+        return w
 
     def set_profiling(self, on):
         self._check(self.L.eagle_set_profiling(self._h, int(on)), "set_profiling")

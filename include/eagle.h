@@ -173,7 +173,7 @@ int eagle_clip_close(EagleHandle* h);
 
 /* ---- track identities: self.tracker.update(dets, frame) of cm.py:66-72, 574-596 -----------------------------------
  * BoT-SORT's motion / IoU association (constant-velocity Kalman filter, high / low confidence sets, three assignments, life cycle);
- * appearance ReID and ECC camera-motion compensation are off (stated deviations).  eagle_track_frames walks n records of ONE
+ * appearance ReID is off and camera-motion compensation uses sparse LK instead of ECC (eagle_clip_motion below; stated deviations).  eagle_track_frames walks n records of ONE
  * clip in frame order (call it chunk after chunk; eagle_track_open starts a new clip): Player / Goalkeeper entries become keyed by
  * track id with the filter's boxes and feet (cm.py:577-596; frames on which the tracker reports no player keep the detection-index
  * fallback of cm.py:598-616), then the pitch coordinates of the moved foot points are recomputed on the GPU with each record's H. */
@@ -183,6 +183,12 @@ typedef struct EagleTrackParams {
 } EagleTrackParams;
 int eagle_track_open(EagleHandle* h, const EagleTrackParams* params /* NULL: defaults */);
 int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n);
+/* Camera-motion compensation (BoT-SORT's gmc step; boxmot's default estimates the warp with ECC, here: a similarity transform from an 8 x 6 grid
+ * of points tracked by the key-point cadence's pyramidal LK kernel, RANSAC over point pairs + least squares on the consensus set — stated deviation).
+ * eagle_clip_motion: needs an open clip session (eagle_clip_open); warps[6 * i .. +5] = row-major 2 x 3 warp of frame first+i-1 -> first+i
+ * (identity for clip frame 0).  eagle_track_frames_cmc: as eagle_track_frames, applying warps[6 * i] to all track states before frame i is associated. */
+int eagle_clip_motion(EagleHandle* h, int first, int count, double* warps);
+int eagle_track_frames_cmc(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps /* NULL: none */);
 
 /* ---- team colours: Processor.detect_color, eagle/processor.py:466-503, for player crops of a clip resident in HBM -----
  * counts[12 * i + k]: pixels of crop i's player cluster inside colour range k of proc.py:10-23, k = red (red2 merged), orange, yellow,

@@ -4,9 +4,12 @@ BoT-SORT track association as the reference runs it behind ``self.tracker.update
 (eagle/models/coordinate_model.py:66-72, 574-596; boxmot 15.0.2 ``BotSort``, uv.lock:98-99 — NOT in /root/reference and absent from
 this image: restated from the published algorithm (Aharon et al. 2022; ByteTrack's two-stage association), PARITY UNPINNED).
 
-Stated deviations from the reference's configuration: appearance (OSNet ReID, ``with_reid=True``) and camera-motion
-compensation (ECC) are OFF — both need data this build does not have (the ReID checkpoint, cv2).  What remains is the motion /
-IoU part of BoT-SORT exactly as published:
+Stated deviations from the reference's configuration: appearance (OSNet ReID, ``with_reid=True``) is OFF (the checkpoint does
+not exist here).  Camera-motion compensation: boxmot's default is ECC on the gray frame (cv2, absent); here the warp is a similarity transform
+estimated from a fixed 8 x 6 grid of points tracked by the pyramidal LK of the key-point cadence (``camera_motion``: the same K12 kernel on the
+GPU side), RANSAC over point pairs + least squares on the consensus set — BoT-SORT's own "sparseOptFlow" alternative with a fixed grid instead
+of a corner detector.  The warp is applied as BoT-SORT's ``multi_gmc`` does (means and covariances of all pooled and unconfirmed tracks, after
+the prediction step).  What remains is the motion / IoU part of BoT-SORT exactly as published:
 
   * constant-velocity Kalman filter on (cx, cy, w, h) with BoT-SORT's noise scaling (std_weight_position 1/20, std_weight_velocity 1/160);
   * detections split by confidence: high (> track_high_thresh 0.5) and low (track_low_thresh 0.1 < c < 0.5);
@@ -52,6 +55,86 @@ class _KF:
         S = _KF.H @ cov @ _KF.H.T + np.diag(np.square(std))
         K = np.linalg.solve(S, (cov @ _KF.H.T).T).T
         return mean + K @ (z - pm), cov - K @ S @ K.T
+
+
+GRID_W, GRID_H = 8, 6          # camera-motion grid (48 points: one LK launch of the key-point kernel)
+
+
+def motion_grid(frame_h, frame_w):
+    """centres of an 8 x 6 cell grid, truncated to whole pixels (the flow operator takes integer key-points), float32 (x, y) rows in row-major cell order"""
+    return np.array([[np.floor((i + 0.5) * frame_w / GRID_W), np.floor((j + 0.5) * frame_h / GRID_H)] for j in range(GRID_H) for i in range(GRID_W)], np.float32)
+
+
+def similarity_ransac(p0, p1, iters=200, thresh=3.0):
+    """2 x 3 similarity [[a, -b, tx], [b, a, ty]] mapping p0 -> p1 (float64): 200 two-point hypotheses drawn by a fixed LCG, the one with the
+    most residuals < 3 px wins (first on ties), least squares on its consensus set.  Every sum runs in index order (the C++ side repeats it
+    operation by operation).  Fewer than two pairs, or no hypothesis: identity."""
+    p0 = np.asarray(p0, np.float64).reshape(-1, 2); p1 = np.asarray(p1, np.float64).reshape(-1, 2)
+    n = len(p0)
+    ident = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    if n < 2:
+        return ident
+    state = 12345
+    best_cnt, best = -1, None
+    for _ in range(iters):
+        state = (state * 1103515245 + 12345) & 0x7FFFFFFF; i = (state >> 8) % n
+        state = (state * 1103515245 + 12345) & 0x7FFFFFFF; j = (state >> 8) % n
+        if i == j:
+            continue
+        dx0, dy0 = p0[j, 0] - p0[i, 0], p0[j, 1] - p0[i, 1]
+        dx1, dy1 = p1[j, 0] - p1[i, 0], p1[j, 1] - p1[i, 1]
+        den = dx0 * dx0 + dy0 * dy0
+        if den < 1e-9:
+            continue
+        a = (dx0 * dx1 + dy0 * dy1) / den; b = (dx0 * dy1 - dy0 * dx1) / den
+        tx = p1[i, 0] - (a * p0[i, 0] - b * p0[i, 1]); ty = p1[i, 1] - (b * p0[i, 0] + a * p0[i, 1])
+        cnt = 0
+        for k in range(n):
+            ex = a * p0[k, 0] - b * p0[k, 1] + tx - p1[k, 0]; ey = b * p0[k, 0] + a * p0[k, 1] + ty - p1[k, 1]
+            cnt += (ex * ex + ey * ey) < thresh * thresh
+        if cnt > best_cnt:
+            best_cnt, best = cnt, (a, b, tx, ty)
+    if best is None:
+        return ident
+    a, b, tx, ty = best
+    idx = [k for k in range(n) if (a * p0[k, 0] - b * p0[k, 1] + tx - p1[k, 0]) ** 2 + (b * p0[k, 0] + a * p0[k, 1] + ty - p1[k, 1]) ** 2 < thresh * thresh]
+    if len(idx) < 2:
+        return ident
+    m = float(len(idx))
+    c0x = c0y = c1x = c1y = 0.0
+    for k in idx:
+        c0x += p0[k, 0]; c0y += p0[k, 1]; c1x += p1[k, 0]; c1y += p1[k, 1]
+    c0x /= m; c0y /= m; c1x /= m; c1y /= m
+    sxx = sdot = scross = 0.0
+    for k in idx:
+        qx, qy, rx, ry = p0[k, 0] - c0x, p0[k, 1] - c0y, p1[k, 0] - c1x, p1[k, 1] - c1y
+        sxx += qx * qx + qy * qy; sdot += qx * rx + qy * ry; scross += qx * ry - qy * rx
+    if sxx < 1e-9:
+        return ident
+    a, b = sdot / sxx, scross / sxx
+    return np.array([[a, -b, c1x - (a * c0x - b * c0y)], [b, a, c1y - (b * c0x + a * c0y)]])
+
+
+def camera_motion(prev_bgr, cur_bgr):
+    """the warp of frame t-1 -> t: LK (cm.py's parameters) on the grid, pairs with status 1 -> similarity_ransac"""
+    from . import prims as P
+    g0, g1 = P.bgr2gray(prev_bgr), P.bgr2gray(cur_bgr)
+    pts = motion_grid(*g0.shape)
+    nxt, st = P.calc_optical_flow_pyr_lk(g0, g1, pts)
+    ok = st[:, 0] == 1
+    return similarity_ransac(pts[ok], nxt[ok])
+
+
+def apply_warp(tracks, warp):
+    """BoT-SORT's STrack.multi_gmc: R8 = kron(I4, R) on the 8-state (it rotates (w, h) and the velocities too), t added to (cx, cy)"""
+    if warp is None or not tracks:
+        return
+    R = np.asarray(warp, np.float64)[:, :2]; t = np.asarray(warp, np.float64)[:, 2]
+    R8 = np.kron(np.eye(4), R)
+    for tr in tracks:
+        tr.mean = R8 @ tr.mean
+        tr.mean[:2] += t
+        tr.cov = R8 @ tr.cov @ R8.T
 
 
 class _Track:
@@ -114,8 +197,9 @@ class BotSortLite:
         t.state, t.is_activated, t.frame_id = TRACKED, True, self.frame_id
         t.conf, t.cls, t.det_ind = d.conf, d.cls, d.det_ind
 
-    def update(self, dets):
-        """dets: [n,6] x1,y1,x2,y2,conf,cls -> [m,8] x1,y1,x2,y2,id,conf,cls,det_ind (as boxmot returns it)."""
+    def update(self, dets, warp=None):
+        """dets: [n,6] x1,y1,x2,y2,conf,cls -> [m,8] x1,y1,x2,y2,id,conf,cls,det_ind (as boxmot returns it).  warp: optional 2 x 3 camera
+        motion of the previous frame -> this one (applied after the prediction, like BoT-SORT's gmc)."""
         self.frame_id += 1
         dets = np.asarray(dets, np.float64).reshape(-1, 6)
         first = [_Track(d, i) for i, d in enumerate(dets) if d[4] > self.hi]
@@ -127,6 +211,8 @@ class BotSortLite:
             if t.state != TRACKED:
                 t.mean[6] = 0.0; t.mean[7] = 0.0
             t.mean, t.cov = _KF.predict(t.mean, t.cov)
+        apply_warp(pool, warp)
+        apply_warp(unconfirmed, warp)
         activated, refind, lost_now, removed = [], [], [], []
         m, ut, ud = _assign(_iou_cost(pool, first), self.match)
         for i, j in m:

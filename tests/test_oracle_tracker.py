@@ -67,3 +67,49 @@ def test_objects_follow_cm_577_596():
     for tid, o in obj["Player"].items():
         x1, y1, x2, y2 = o["BBox"]
         assert o["Bottom_center"] == [int((x1 + x2) / 2), y2] and 0 <= x1 <= x2 < track_cases.W
+
+
+def test_similarity_ransac_recovers_a_known_camera_motion():
+    """oracle/tracker.py::similarity_ransac: rotation + zoom + shift under pixel noise and 20 % gross outliers."""
+    import numpy as np
+    from oracle import tracker as T
+    rng = np.random.default_rng(0)
+    p0 = rng.uniform(0, 1000, (40, 2)); th, sc = 0.01, 1.02
+    R = np.array([[sc * np.cos(th), -sc * np.sin(th)], [sc * np.sin(th), sc * np.cos(th)]]); t = np.array([12.5, -7.25])
+    p1 = p0 @ R.T + t + rng.normal(0, 0.2, p0.shape)
+    p1[:8] += rng.uniform(-80, 80, (8, 2))
+    W = T.similarity_ransac(p0, p1)
+    assert np.abs(W[:, :2] - R).max() < 2e-4 and np.abs(W[:, 2] - t).max() < 0.15
+    assert np.array_equal(T.similarity_ransac(p0[:1], p1[:1]), np.array([[1.0, 0, 0], [0, 1.0, 0]]))
+
+
+def test_camera_motion_follows_the_synthetic_camera():
+    """camera_motion (sparse LK on the 8 x 6 grid + RANSAC) between two frames of the panning synthetic camera: the warp maps the projections of pitch
+    points at time t onto their projections at time t + 2 to within a pixel or two."""
+    import numpy as np
+    from eagle_amd import synth
+    from oracle import tracker as T
+    a, b = synth.frame(0, 4), synth.frame(0, 6)
+    W = T.camera_motion(a, b)
+    world = np.array([[x, y] for x in (20.0, 40.0, 52.5, 65.0, 85.0) for y in (10.0, 34.0, 58.0)])
+    pa, pb = synth.project(synth.camera(0, 4), world), synth.project(synth.camera(0, 6), world)
+    inside = (pa[:, 0] > 0) & (pa[:, 0] < 1280) & (pa[:, 1] > 0) & (pa[:, 1] < 720)
+    pred = pa[inside] @ W[:, :2].T + W[:, 2]
+    assert inside.sum() >= 6 and np.abs(pred - pb[inside]).max() < 3.0, np.abs(pred - pb[inside]).max()
+
+
+def test_camera_motion_compensation_keeps_identities_under_a_fast_pan():
+    """A pan of a box width per frame: with the warps every object keeps ONE id for the whole clip; without them tracks are lost and re-born."""
+    import track_cases
+    from oracle.tracker import BotSortLite
+    clip, warps = track_cases.pan(track_cases.make_clip("parallel", 30))
+
+    def ids_per_object(use_warp):
+        tr = BotSortLite(); seen = {}
+        for i, d in enumerate(clip):
+            for row in tr.update(d, warps[i].reshape(2, 3) if use_warp else None):
+                seen.setdefault(int(row[7]), set()).add(int(row[4]))        # detection index (stable per object in this clip) -> ids
+        return seen
+    with_cmc, without = ids_per_object(True), ids_per_object(False)
+    assert all(len(v) == 1 for v in with_cmc.values()) and len(with_cmc) >= 9
+    assert sum(len(v) for v in without.values()) > sum(len(v) for v in with_cmc.values())

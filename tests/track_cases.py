@@ -54,3 +54,15 @@ def make_clip(name, n=48):
 
 
 CLIPS = ["parallel", "crossing", "occlusion", "births", "lowconf", "crowd"]
+
+
+def pan(clip, dx=42.0, dy=-9.0):
+    """The same detections seen by a camera that pans by (dx, dy) pixels per frame, and the per-frame warps a camera-motion estimator would
+    report (frame i-1 -> i; identity for frame 0): without compensation the constant-velocity filter has to absorb a jump of a box width."""
+    out, warps = [], []
+    for i, d in enumerate(clip):
+        e = d.copy()
+        e[:, [0, 2]] += np.float32(dx * i); e[:, [1, 3]] += np.float32(dy * i)
+        out.append(e)
+        warps.append([1.0, 0.0, dx if i else 0.0, 0.0, 1.0, dy if i else 0.0])
+    return out, np.array(warps, np.float64)

@@ -281,7 +281,7 @@ def test_f16_family_record_parity_cfg2(state_dicts):
     from oracle import pipeline
     hs, ys = state_dicts
     hs2, g = _peaked_state_dict(hs)
-    frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 9)])      # (two frames: each costs a minute of fp16-emulating CPU oracle)
+    frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 4), synth.frame(0, 9)])
     cm = CoordinateModel(precision="f16", batch=2, hrnet_state_dict=hs2, detector_state_dict=ys)
     recs = cm.process_records(frames)
     cm.handle.close()

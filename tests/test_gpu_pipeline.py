@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def frames():
     from eagle_amd import synth
-    return np.stack([synth.frame(0, 0), synth.frame(0, 37), synth.noise_frame(1)])
+    return np.stack([synth.frame(0, 0), synth.frame(0, 37), synth.noise_frame(1), synth.frame(0, 12), synth.frame(2, 5)])
 
 
 @pytest.fixture(scope="module")
@@ -281,7 +281,7 @@ def test_f16_family_record_parity_cfg2(state_dicts):
     from oracle import pipeline
     hs, ys = state_dicts
     hs2, g = _peaked_state_dict(hs)
-    frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 4), synth.frame(0, 9)])
+    frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 4), synth.frame(0, 9), synth.frame(0, 1), synth.frame(0, 6), synth.frame(0, 14)])
     cm = CoordinateModel(precision="f16", batch=2, hrnet_state_dict=hs2, detector_state_dict=ys)
     recs = cm.process_records(frames)
     cm.handle.close()

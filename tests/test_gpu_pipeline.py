@@ -95,6 +95,31 @@ def test_batch_invariance(state_dicts, frames):
     assert ra.tobytes() == rb.tobytes() == rb2.tobytes()
 
 
+def test_full_size_clip_properties(state_dicts):
+    """BASELINE.json's configs[1] at full size (1000 frames of 1280x720, device batch 50, the bench's clip: 20 distinct frames tiled): every copy of a
+    frame yields byte-identical records wherever it sits in the clip and in its batch; a different device batch (37: ragged last batch) yields the
+    same 1000 records; and the host-fed path (pageable memory through the pinned ring) equals the resident path."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    base = np.stack([synth.frame(0, t) for t in range(20)])
+    clip = np.ascontiguousarray(np.tile(base, (50, 1, 1, 1)))
+    a = CoordinateModel(precision="f16", batch=50, hrnet_state_dict=hs, detector_state_dict=ys)
+    ra = a.process_records(clip)                                  # host frames: eagle_process_frames
+    d = a.handle.upload(clip)
+    rd = np.zeros(len(clip), ra.dtype)
+    a.handle.process_device(d, len(clip), rd)                     # resident frames: eagle_process_device_frames
+    a.handle.free(d); a.handle.close()
+    assert ra.tobytes() == rd.tobytes()
+    for t in range(20):
+        first = ra[t].tobytes()
+        assert all(ra[k].tobytes() == first for k in range(t, 1000, 20)), t
+    b = CoordinateModel(precision="f16", batch=37, hrnet_state_dict=hs, detector_state_dict=ys)
+    rb = b.process_records(clip)
+    b.handle.close()
+    assert ra.tobytes() == rb.tobytes()
+
+
 def test_rccl_gather_single_rank(state_dicts):
     """eagle_comm_id / eagle_comm_init / eagle_gather through the real RCCL library (world size 1 on this box)."""
     from eagle_amd import lib

@@ -240,3 +240,36 @@ def test_lk_bit_exact_while_another_handle_runs_the_networks(model, force, state
             t.join()
         h.clip_close(); h.free(d)
         co.handle.close()
+
+
+def test_full_size_clip_cadence_properties(state_dicts):
+    """BASELINE.json's 1000-frame clip through the reference's default cadence at 25 fps (HRNet on every 8th frame, LK + loop body per frame,
+    homography once per second): the records do not depend on the device batch (50 -> chunks of 400 frames, 8 -> chunks of 64: different
+    chunking of the asynchronous network passes under the sequential loop), a second run repeats them byte for byte, and every frame's detector
+    part equals the stateless path's (the detector runs on every frame in both)."""
+    from eagle_amd import synth
+    hs, ys = state_dicts
+    base = np.stack([synth.frame(0, t) for t in range(40)])
+    clip = np.ascontiguousarray(np.concatenate([base, base[::-1]] * 13)[:1000])          # a camera that pans forth and back
+    runs = []
+    for batch in (50, 8):
+        m = CoordinateModel(precision="f16", batch=batch, hrnet_state_dict=hs, detector_state_dict=ys)
+        try:
+            stats = {}
+            runs.append((m.flow_records(clip, 8, 25, stats=stats).copy(), stats["detected_frames"]))
+            if batch == 50:
+                again = m.flow_records(clip, 8, 25).copy()
+                stateless = m.process_records(clip[:100])
+        finally:
+            m.handle.close()
+    (ra, da), (rb, db) = runs
+    assert da == db and len(da) >= 125
+
+    def same(a, b):          # every named field (the loop kernel assigns whole structs, so the padding bytes between fields are not defined)
+        return all(a[name].tobytes() == b[name].tobytes() for name in a.dtype.names)
+    assert same(ra, rb) and same(ra, again)
+    for i in range(100):
+        n = int(ra[i]["n_det"])
+        assert n == int(stateless[i]["n_det"])
+        for f in ("x1", "y1", "x2", "y2", "conf", "cls"):
+            assert np.array_equal(ra[i]["det"][f][:n], stateless[i]["det"][f][:n]), (i, f)

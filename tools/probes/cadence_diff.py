@@ -24,3 +24,17 @@ def diff(a, b, tag):
                 print("   first differing frame", i, "field", name, np.asarray(a[i][name]).ravel()[:8], np.asarray(b[i][name]).ravel()[:8])
 diff(out[50], out["again"], "batch 50 run 1 vs run 2:")
 diff(out[50], out[8], "batch 50 vs batch 8:")
+a = np.frombuffer(out[50].tobytes(), np.uint8).reshape(1000, -1); b = np.frombuffer(out["again"].tobytes(), np.uint8).reshape(1000, -1)
+offs = np.nonzero((a != b).any(0))[0]
+print("record size", a.shape[1], "differing byte offsets:", len(offs), offs[:40])
+dt = out[50].dtype
+for name in dt.names:
+    o = dt.fields[name][1]; sz = dt.fields[name][0].itemsize
+    hit = [int(x) for x in offs if o <= x < o + sz]
+    if hit:
+        print("  inside field", name, "offset", o, "size", sz, "->", hit[:10])
+        sub = dt.fields[name][0]
+        if sub.subdtype and sub.subdtype[0].names:
+            el = sub.subdtype[0]; per = el.itemsize
+            rel = sorted({(h - o) % per for h in hit})
+            print("     element size", per, "relative offsets", rel[:16], "field map", {n: el.fields[n][1] for n in el.names})

@@ -39,7 +39,7 @@ def main(argv=None):
     ap.add_argument("--out", default="output/synthetic")
     ap.add_argument("--detector", default="n")
     ap.add_argument("--imgsz", type=int, default=640)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "f32", "f32s"])
     ap.add_argument("--batch", type=int, default=10)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--num-homography", type=int, default=1, help="homography solves per second (main.py:27: 1)")

@@ -26,7 +26,7 @@ class CoordinateModel:
         self.batch = batch
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
                                  det_imgsz=det_imgsz, batch=batch,
-                                 precision=lib.PREC_F16 if precision == "f16" else lib.PREC_F32,
+                                 precision=lib.PRECISIONS[precision],
                                  keypoint_conf=keypoint_conf, detector_conf=detector_conf,
                                  detector_floor=min(detector_conf, 0.15), use_graph=int(use_graph))
         # the reference reads eagle/models/weights/*.pt|.pth (cm.py:55-59); none exist here -> seeded synthetic

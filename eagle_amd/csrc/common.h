@@ -38,7 +38,8 @@ struct TView {
     int c = 0;           // channels of this view (padded to the kernel granularity)
     int cs = 0;          // channel stride (elements per pixel) of the underlying buffer
     int off = 0;         // first channel of the view
-    int f32 = 0;         // element type: 0 fp16, 1 fp32
+    int f32 = 0;         // element type: 0 fp16, 1 fp32, 2 split fp32 (EAGLE_PREC_F32S: per 8 channels 32 bytes, [hi x 8][lo x 8] binary16 with
+                         // hi = rn(16 v), lo = rn(16 v - hi); c / cs / off stay in logical channels, multiples of 8)
     size_t esize() const { return f32 ? 4 : 2; }
     TView slice(int o, int cc) const { TView v = *this; v.off = off + o; v.c = cc; return v; }
 };
@@ -61,6 +62,7 @@ struct ConvLaunch {
     int pre_act = 0, post_act = 0;
     int out_f32 = 0;         // store fp32 regardless of precision (logits)
     double flop = 0;         // algorithmic 2*MAC (unpadded)
+    float descale = 1.0f;    // EAGLE_PREC_F32S: returned by conv_tile_weights for this layer's weight image
     // fp16 family, head convolution: instead of storing the logits, every workgroup reduces sigmoid(logit) of its tile to one
     // (maximum, first index) per channel and writes it to (*am_slot)[(frame * tiles + tile) * cout_pad + channel] (K5 fused into the
     // producer: the fp32 logit tensor never goes to HBM).  The slot is read when the launch is enqueued.
@@ -74,7 +76,11 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s);
 size_t conv_weight_elems(int precision, const ConvConfig& cfg);
 size_t conv_lds_bytes(int precision, const ConvConfig& cfg);
 // w_hwio: folded fp32 weights [ks][ks][cin_real][cout_real]; dst: host buffer of conv_weight_elems elements
-void conv_tile_weights(int precision, const ConvConfig& cfg, const float* w_hwio, int cin_real, int cout_real, void* dst);
+// EAGLE_PREC_F32S: the weights are scaled by a power of two (largest magnitude into [2^14, 2^15)) and split into hi / lo binary16 parts;
+// *descale receives 2^-(that exponent + 4) (the 4: the activations' own scaling), which the kernel applies to the accumulator
+void conv_tile_weights(int precision, const ConvConfig& cfg, const float* w_hwio, int cin_real, int cout_real, void* dst, float* descale = nullptr);
+inline int prec_tensor_fmt(int precision) { return precision == EAGLE_PREC_F32 ? 1 : precision == EAGLE_PREC_F32S ? 2 : 0; }
+inline bool prec_is_f16_kernels(int precision) { return precision == EAGLE_PREC_F16 || precision == EAGLE_PREC_F32S; }
 // plain_epilogue: pre_act none, post_act none/ReLU, at most one residual, fp16 output (what the weight-stationary kernel implements)
 ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue = false, bool second_residual = false);
 

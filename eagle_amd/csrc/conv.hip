@@ -14,6 +14,7 @@
 //     accumulates these as a k-ordered fmaf chain, so outputs are bit-identical to oracle/eo_prims.c.
 // Epilogue: v = acc + bias; v = pre(v); v = r1 + v; v = v + r2; v = post(v); store (fp16 RNE / fp32).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 
@@ -48,6 +49,11 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
         const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 2 + 16);        // output transpose, one strip per wave
         return conv_ws(c) ? operands + strips + 16 : std::max(operands + 16, strips);
     }
+    if (precision == EAGLE_PREC_F32S) {                    // hi and lo fragment blocks per K-step; 2 * kc fp16 values per staged pixel; 4-byte outputs
+        const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 2 * 4 * bn * 16 + (size_t)hh * hw * f16_ps(2 * c.kc);
+        const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 4 + 16);
+        return std::max(operands + 16, strips);
+    }
     return (size_t)c.ks * c.ks * (c.kc / 4) * 4 * bn * 4 + (size_t)hh * hw * (c.kc + 1) * 4;
 }
 
@@ -75,9 +81,9 @@ static const Inst* find_inst(int precision, const ConvConfig& c)
     auto match = [&](const Inst& i) { return i.prec == precision && i.ks == c.ks && i.s == c.stride && i.kc == c.kc && i.nt == c.nt && i.variant == c.variant; };
     for (const Inst& i : g_ad_inst)
         if (match(i)) return &i;
-    for (int part = 0; part < 4; ++part) {
+    for (int part = 0; part < 7; ++part) {
         int n = 0;
-        const Inst* t = conv_inst_part(part, &n);
+        const Inst* t = part < 4 ? conv_inst_part(part, &n) : part == 4 ? conv_inst_split0(&n) : part == 5 ? conv_inst_split1(&n) : conv_inst_split2(&n);
         for (int k = 0; k < n; ++k)
             if (match(t[k])) return &t[k];
     }
@@ -104,6 +110,32 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         for (int nt : nts)
             if (cout_pad % (16 * nt) == 0) { c.nt = nt; break; }
         c.kc = (cin_pad < 16) ? 4 : 16;
+        return c;
+    }
+    if (precision == EAGLE_PREC_F32S) {
+        // split family: generic kernel, full (variant 0) or half (variant 3) tiles; the (NT, KC) pair with the most MFMA work per staged byte
+        // whose LDS footprint lets two workgroups share a CU.  EAGLE_CONV_FORCE applies as below.
+        if (const char* f = getenv("EAGLE_CONV_FORCE")) {
+            ConvConfig q = c;
+            if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 && find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024)
+                return q;
+        }
+        static const int skcs[] = {32, 16, 8};
+        long best = -1;
+        c.nt = 1; c.kc = 8; c.variant = 0;
+        for (int variant : {0, 3})
+            for (int nt : nts) {
+                if (cout_pad % (16 * nt)) continue;
+                for (int kc : skcs) {
+                    if (cin_pad % kc) continue;
+                    ConvConfig t = c; t.nt = nt; t.kc = kc; t.variant = variant;
+                    if (!find_inst(precision, t)) continue;
+                    if (lds_bytes(precision, t) > 80 * 1024) continue;
+                    if (nt * conv_pw(t) > 12) continue;                    // registers: 4 accumulator VGPRs per (NT, PW) pair next to twice the fragments of the fp16 kernel
+                    const long score = (long)nt * conv_pw(t) * 1000 + kc * 10 + (variant == 0 ? 1 : 0);
+                    if (score > best) { best = score; c.nt = nt; c.kc = kc; c.variant = variant; }
+                }
+            }
         return c;
     }
     // developer override (parity tests of a specific kernel variant): EAGLE_CONV_FORCE="kc,nt,variant"
@@ -157,15 +189,43 @@ size_t conv_weight_elems(int precision, const ConvConfig& c)
     if (precision == EAGLE_PREC_F16 && conv_ad(c) && c.stride == 2) return (size_t)(c.cout_pad / (c.nt * 16)) * (4 * c.cin / 32) * 16 * (c.nt * 16) * 8;
     const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc;
     if (precision == EAGLE_PREC_F16) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 4 * bn * 8;
+    if (precision == EAGLE_PREC_F32S) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 2 * 4 * bn * 8;      // fp16 elements: a hi and a lo block per K-step
     return (size_t)nblk * nch * c.ks * c.ks * (c.kc / 4) * 4 * bn;
 }
 
-void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int cin_real, int cout_real, void* dst)
+void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int cin_real, int cout_real, void* dst, float* descale)
 {
     const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc, taps = c.ks * c.ks;
     auto W = [&](int tap, int ci, int co) -> float {
         return (ci < cin_real && co < cout_real) ? w[((size_t)tap * cin_real + ci) * cout_real + co] : 0.0f;
     };
+    if (descale) *descale = 1.0f;
+    if (precision == EAGLE_PREC_F32S) {
+        // [Cout block][Cin chunk][K-step][hi | lo][q][BN][8]; K-step i, lane group q: (tap, channel group) pair 4 i + q in (tap-major) order
+        float amax = 0.f;
+        for (size_t k = 0; k < (size_t)taps * cin_real * cout_real; ++k) amax = std::max(amax, std::fabs(w[k]));
+        int e = 0;
+        if (amax > 0.f) (void)std::frexp(amax, &e);                        // amax in [2^(e-1), 2^e)
+        const int sw = 15 - e;                                             // scaled maximum in [2^14, 2^15)
+        const float scale = std::ldexp(1.0f, sw);
+        if (descale) *descale = std::ldexp(1.0f, -(sw + 4));
+        const int G = c.kc / 8, NGR = taps * G, NI = f16_ni(c.ks, c.kc);
+        _Float16* d = (_Float16*)dst;
+        for (int b = 0; b < nblk; ++b)
+            for (int ch = 0; ch < nch; ++ch)
+                for (int i = 0; i < NI; ++i)
+                    for (int part = 0; part < 2; ++part)
+                        for (int qq = 0; qq < 4; ++qq)
+                            for (int nn = 0; nn < bn; ++nn)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int g = 4 * i + qq;
+                                    float v = 0.f;
+                                    if (g < NGR) { const int tap = g / G, cg = g % G; v = W(tap, ch * c.kc + cg * 8 + j, b * bn + nn) * scale; }
+                                    const _Float16 hi = (_Float16)v;
+                                    *d++ = part == 0 ? hi : (_Float16)(v - (float)hi);
+                                }
+        return;
+    }
     if (precision == EAGLE_PREC_F16 && conv_ad(c) && c.stride == 2) {
         // space-to-depth form: [Cout block][chunk of 32 s2d channels][tap' (2x2) * 4 + channel group][BN][8]; s2d channel = phase * Cin + channel,
         // phase = 2 * ry + rx; tap' row 0 is the s2d row above (only its odd phase contributes: ky = 0), tap' row 1 the same row (ky = 1, 2)
@@ -241,6 +301,13 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.y = L.y.p; a.ycs = L.y.cs; a.yoff = L.y.off; a.Ho = L.y.h; a.Wo = L.y.w;
     a.r1 = L.r1.p; a.r1cs = L.r1.cs; a.r1off = L.r1.off;
     a.r2 = L.r2.p; a.r2cs = L.r2.cs; a.r2off = L.r2.off;
+    a.descale = L.descale;
+    if (precision == EAGLE_PREC_F32S) {                     // the kernels address split tensors in fp16 elements: two per logical channel
+        if (L.x.f32 != 2 || (L.r1.p && L.r1.f32 != 2) || (L.r2.p && L.r2.f32 != 2) || L.y.f32 != (L.out_f32 ? 1 : 2))
+            fail(EAGLE_E_INVALID, "split conv: operand tensor formats do not match the family");
+        a.xcs *= 2; a.xoff *= 2; a.r1cs *= 2; a.r1off *= 2; a.r2cs *= 2; a.r2off *= 2;
+        if (!L.out_f32) { a.ycs *= 2; a.yoff *= 2; }
+    }
     if (!a.r1 && a.r2) { a.r1 = a.r2; a.r1cs = a.r2cs; a.r1off = a.r2off; a.r2 = nullptr; }       // a single residual is always operand 1 (IEEE addition is commutative: same bits)
     a.pre_act = L.pre_act; a.post_act = L.post_act; a.out_f32 = L.out_f32 || precision == EAGLE_PREC_F32;
     a.wx = c.wx;
@@ -268,11 +335,11 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         HIP_CHECK(hipGetLastError());
         return;
     }
-    if (a.am && (precision != EAGLE_PREC_F16 || conv_ws(c)))
+    if (a.am && (!prec_is_f16_kernels(precision) || conv_ws(c)))
         fail(EAGLE_E_NOKERNEL, "fused heat-map maxima need the generic fp16 kernel");
-    if (precision == EAGLE_PREC_F16) {                      // the fp16 kernels address tensors through raw buffer descriptors with 32-bit byte offsets
+    if (prec_is_f16_kernels(precision)) {                   // the fp16 kernels address tensors through raw buffer descriptors with 32-bit byte offsets
         const size_t lim = (size_t)1 << 31;
-        const size_t cs_out = std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0);
+        const size_t cs_out = std::max(std::max(a.out_f32 ? 2 * a.ycs : a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0);
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * cs_out * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
     }
@@ -292,7 +359,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     static const int xcd_env = getenv("EAGLE_CONV_XCD") ? atoi(getenv("EAGLE_CONV_XCD")) : 1;
     // 1x1 layers with several Cout blocks re-read their input tile once per block: in tile-major / block-minor order on one XCD the
     // re-reads hit that XCD's L2 instead of HBM
-    a.xcd = (precision == EAGLE_PREC_F16 && !conv_ws(c) && (c.ks == 3 || (c.ks == 1 && gy > 1)) && xcd_env) ? 1 : 0;
+    a.xcd = (prec_is_f16_kernels(precision) && !conv_ws(c) && (c.ks == 3 || (c.ks == 1 && gy > 1)) && xcd_env) ? 1 : 0;
     dim3 grid(gx, gy);
     if (a.xcd) grid = dim3(gx * gy, 1);
     if (conv_ws(c)) grid = dim3(gx, 1);

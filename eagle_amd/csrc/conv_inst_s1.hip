@@ -1,0 +1,24 @@
+// Convolution kernel instances of the split-precision family (EAGLE_PREC_F32S), part 1 of 3: conv_f16_kernel<..., SPLIT = true> (conv_kernels.inc).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "dmath.h"
+#include "conv_internal.h"
+
+namespace eagle {
+
+#include "conv_kernels.inc"
+
+#define IS(KS, S, KC, NT) {EAGLE_PREC_F32S, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4, true>}
+#define ISH(KS, S, KC, NT) {EAGLE_PREC_F32S, KS, S, KC, NT, 3, conv_f16_kernel<KS, S, KC, NT, false, 2, true>}
+#define ALLS(KS, S, KC) IS(KS, S, KC, 1), IS(KS, S, KC, 2), IS(KS, S, KC, 3), IS(KS, S, KC, 4), IS(KS, S, KC, 6)
+#define ALLSH(KS, S, KC) ISH(KS, S, KC, 1), ISH(KS, S, KC, 2), ISH(KS, S, KC, 3), ISH(KS, S, KC, 4), ISH(KS, S, KC, 6)
+
+static const Inst g_split1[] = {
+    // 3x3 stride 2 (the 3-channel stems have kc = 8)
+    ALLS(3, 2, 8), ALLS(3, 2, 16), ALLSH(3, 2, 8), ALLSH(3, 2, 16), ALLSH(3, 2, 32),
+};
+const Inst* conv_inst_split1(int* n) { *n = (int)(sizeof(g_split1) / sizeof(g_split1[0])); return g_split1; }
+
+}  // namespace eagle

@@ -1,0 +1,24 @@
+// Convolution kernel instances of the split-precision family (EAGLE_PREC_F32S), part 2 of 3: conv_f16_kernel<..., SPLIT = true> (conv_kernels.inc).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "dmath.h"
+#include "conv_internal.h"
+
+namespace eagle {
+
+#include "conv_kernels.inc"
+
+#define IS(KS, S, KC, NT) {EAGLE_PREC_F32S, KS, S, KC, NT, 0, conv_f16_kernel<KS, S, KC, NT, false, 4, true>}
+#define ISH(KS, S, KC, NT) {EAGLE_PREC_F32S, KS, S, KC, NT, 3, conv_f16_kernel<KS, S, KC, NT, false, 2, true>}
+#define ALLS(KS, S, KC) IS(KS, S, KC, 1), IS(KS, S, KC, 2), IS(KS, S, KC, 3), IS(KS, S, KC, 4), IS(KS, S, KC, 6)
+#define ALLSH(KS, S, KC) ISH(KS, S, KC, 1), ISH(KS, S, KC, 2), ISH(KS, S, KC, 3), ISH(KS, S, KC, 4), ISH(KS, S, KC, 6)
+
+static const Inst g_split2[] = {
+    // 1x1
+    ALLS(1, 1, 16), ALLS(1, 1, 32), ALLSH(1, 1, 16), ALLSH(1, 1, 32), ALLSH(1, 1, 64),
+};
+const Inst* conv_inst_split2(int* n) { *n = (int)(sizeof(g_split2) / sizeof(g_split2[0])); return g_split2; }
+
+}  // namespace eagle

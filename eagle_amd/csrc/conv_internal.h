@@ -23,6 +23,7 @@ struct ConvArgs {
     int xcd;                // 1: XCD-aware work order (1-D grid; each XCD owns a contiguous range of (tile, Cout-block) items)
     ArgmaxPart* am;         // fused heat-map maxima (head convolution): partials [frame][tile][am_cs] instead of the output tensor
     int am_cs;
+    float descale;          // EAGLE_PREC_F32S: 2^-(weight scale + 4), undoes the power-of-two operand scaling of the accumulator
     const void* zeros;      // >= 16 zero bytes in global memory (source of out-of-image pixels for unconditional loads / LDS-DMA)
     void* trash;            // >= 4 KiB of scratch global memory (target of out-of-image results for unconditional stores)
 };
@@ -31,6 +32,7 @@ typedef void (*ConvKernel)(ConvArgs);
 struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 const Inst* conv_inst_part(int part, int* n);       // instance tables of conv_inst_0..3.hip (declared per part below)
 const Inst* conv_inst_part0(int* n); const Inst* conv_inst_part1(int* n); const Inst* conv_inst_part2(int* n); const Inst* conv_inst_part3(int* n);
+const Inst* conv_inst_split0(int* n); const Inst* conv_inst_split1(int* n); const Inst* conv_inst_split2(int* n);      // EAGLE_PREC_F32S instances (conv_inst_s0..2.hip)
 // the A-direct kernel instance for (cout_groups x pixel_groups, number of residual operands): wide = 4 x 1 (BN 192), otherwise 2 x 2 (BN 96)
 ConvKernel conv_ad_kernel_s1(bool wide, int n_res);
 ConvKernel conv_ad_kernel_s2(bool wide, int n_res);

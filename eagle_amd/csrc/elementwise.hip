@@ -54,10 +54,24 @@ __device__ __forceinline__ void resize_px(const uint8_t* src, int sh, int sw, in
     }
 }
 
+// EAGLE_PREC_F32S tensors: a value v is stored as hi = rn(16 v), lo = rn(16 v - hi) (binary16), 8 channels = [hi x 8][lo x 8] (32 bytes);
+// hi + lo has at most 23 significant bits, so (hi + lo) / 16 is exact in fp32 and re-splitting a loaded value returns the same pair value.
+struct SplitT { char b[4]; };
+__device__ __forceinline__ void split8_store(void* dst, const float* v)
+{
+    half8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float s = v[i] * 16.0f; hi[i] = (_Float16)s; lo[i] = (_Float16)(s - (float)hi[i]); }
+    *(half8*)dst = hi; *((half8*)dst + 1) = lo;
+}
+
 template <typename T>
 __device__ __forceinline__ void store_px(const TView& v, size_t pix, float r, float g, float b)
 {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
+        const float o[8] = {r, g, b, 0.f, 0.f, 0.f, 0.f, 0.f};
+        split8_store((char*)v.p + (pix * v.cs + v.off) * 4, o);
+    } else if constexpr (sizeof(T) == 2) {
         half8 o = {(_Float16)r, (_Float16)g, (_Float16)b, 0, 0, 0, 0, 0};
         *(half8*)((_Float16*)v.p + pix * v.cs + v.off) = o;
     } else {
@@ -115,6 +129,7 @@ void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w,
     if (total == 0) return;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
     if (precision == EAGLE_PREC_F16) hipLaunchKernelGGL(preprocess_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
+    else if (precision == EAGLE_PREC_F32S) hipLaunchKernelGGL(preprocess_kernel<SplitT>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
     else hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
     HIP_CHECK(hipGetLastError());
 }
@@ -128,6 +143,16 @@ template <> struct Vec<_Float16> {
     float v[8];
     __device__ __forceinline__ void load(const void* p, size_t e) { half8 h = *(const half8*)((const _Float16*)p + e); for (int i = 0; i < 8; ++i) v[i] = (float)h[i]; }
     __device__ __forceinline__ void store(void* p, size_t e) const { half8 h; for (int i = 0; i < 8; ++i) h[i] = (_Float16)v[i]; *(half8*)((_Float16*)p + e) = h; }
+};
+template <> struct Vec<SplitT> {
+    static constexpr int N = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const void* p, size_t e)
+    {
+        const half8 hi = *(const half8*)((const char*)p + e * 4), lo = *(const half8*)((const char*)p + e * 4 + 16);
+        for (int i = 0; i < 8; ++i) v[i] = ((float)hi[i] + (float)lo[i]) * 0.0625f;
+    }
+    __device__ __forceinline__ void store(void* p, size_t e) const { split8_store((char*)p + e * 4, v); }
 };
 template <> struct Vec<float> {
     static constexpr int N = 4;
@@ -204,7 +229,7 @@ void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, c
         a.sh[i] = (y.h > 1) ? (float)(ups[i].z.h - 1) / (float)(y.h - 1) : 0.f;
         a.sw[i] = (y.w > 1) ? (float)(ups[i].z.w - 1) / (float)(y.w - 1) : 0.f;
     }
-    const int vn = y.f32 ? 4 : 8;
+    const int vn = y.f32 == 1 ? 4 : 8;
     const size_t total = (size_t)y.n * y.h * y.w * (y.c / vn);
     size_t biggest = (size_t)y.n * y.h * y.w * std::max(y.cs, base.cs);
     for (int i = 0; i < n_up; ++i) biggest = std::max(biggest, (size_t)ups[i].z.n * ups[i].z.h * ups[i].z.w * ups[i].z.cs);
@@ -219,7 +244,9 @@ void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, c
     default: hipLaunchKernelGGL((fuse_sum_kernel<T_, 3>), grid, dim3(256), 0, s, a); break; \
     }
     if (n_up > 3) fail(EAGLE_E_INVALID, "fuse: at most three low-resolution operands");
-    if (y.f32) { FUSE_LAUNCH(float) } else { FUSE_LAUNCH(_Float16) }
+    if (y.f32 != base.f32) fail(EAGLE_E_INVALID, "fuse: operand formats differ");
+    for (int i = 0; i < n_up; ++i) if (ups[i].z.f32 != y.f32) fail(EAGLE_E_INVALID, "fuse: operand formats differ");
+    if (y.f32 == 1) { FUSE_LAUNCH(float) } else if (y.f32 == 2) { FUSE_LAUNCH(SplitT) } else { FUSE_LAUNCH(_Float16) }
 #undef FUSE_LAUNCH
     HIP_CHECK(hipGetLastError());
 }
@@ -254,9 +281,10 @@ __global__ __launch_bounds__(256) void maxpool5_kernel(TView x, TView y)
 }
 void maxpool5_launch(const TView& x, const TView& y, hipStream_t s)
 {
-    const int vn = x.f32 ? 4 : 8;
+    const int vn = x.f32 == 1 ? 4 : 8;
     const size_t total = (size_t)x.n * x.h * x.w * (x.c / vn);
-    if (x.f32) hipLaunchKernelGGL(maxpool5_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    if (x.f32 == 1) hipLaunchKernelGGL(maxpool5_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    else if (x.f32 == 2) hipLaunchKernelGGL(maxpool5_kernel<SplitT>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
     else hipLaunchKernelGGL(maxpool5_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
     HIP_CHECK(hipGetLastError());
 }
@@ -277,9 +305,10 @@ __global__ __launch_bounds__(256) void upsample2_kernel(TView x, TView y)
 }
 void upsample2_launch(const TView& x, const TView& y, hipStream_t s)
 {
-    const int vn = x.f32 ? 4 : 8;
+    const int vn = x.f32 == 1 ? 4 : 8;
     const size_t total = (size_t)y.n * y.h * y.w * (x.c / vn);
-    if (x.f32) hipLaunchKernelGGL(upsample2_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    if (x.f32 == 1) hipLaunchKernelGGL(upsample2_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    else if (x.f32 == 2) hipLaunchKernelGGL(upsample2_kernel<SplitT>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
     else hipLaunchKernelGGL(upsample2_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
     HIP_CHECK(hipGetLastError());
 }

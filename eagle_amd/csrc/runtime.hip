@@ -221,12 +221,12 @@ struct Builder {
     void set_stream(int k) { cur_stream = k; net->pool = k; }
     void fork_join(Op::Kind kind, int nbranch) { Op op; op.kind = kind; op.nbranch = nbranch; op.tag = kind == Op::FORK ? "fork" : "join"; net->ops.push_back(op); }
 
-    int gran() const { return prec == EAGLE_PREC_F16 ? 8 : 4; }
+    int gran() const { return prec == EAGLE_PREC_F32 ? 4 : 8; }
 
     TView act(int h, int w, int c, bool f32 = false)
     {
         TView v; v.n = N; v.h = h; v.w = w; v.c = c; v.cs = c; v.off = 0;
-        v.f32 = (f32 || prec == EAGLE_PREC_F32) ? 1 : 0;
+        v.f32 = (f32 || prec == EAGLE_PREC_F32) ? 1 : prec_tensor_fmt(prec);
         v.p = net->get((size_t)N * h * w * c * v.esize());
         return v;
     }
@@ -276,8 +276,8 @@ struct Builder {
         if (!conv_supported(prec, L.cfg))
             fail(EAGLE_E_NOKERNEL, "%s: no kernel instance (ks=%d s=%d kc=%d nt=%d)", cname.c_str(), ks, stride, L.cfg.kc, L.cfg.nt);
         const size_t ne = conv_weight_elems(prec, L.cfg);
-        std::vector<char> tiled(ne * (prec == EAGLE_PREC_F16 ? 2 : 4));
-        conv_tile_weights(prec, L.cfg, hwio.data(), cin, cout, tiled.data());
+        std::vector<char> tiled(ne * (prec == EAGLE_PREC_F32 ? 4 : 2));
+        conv_tile_weights(prec, L.cfg, hwio.data(), cin, cout, tiled.data(), &L.descale);
         L.w = net->upload(tiled.data(), tiled.size());
         L.bias = (const float*)net->upload(bias.data(), bias.size() * 4);
         L.x = x;
@@ -300,7 +300,7 @@ struct Builder {
         Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = net->names.back()->c_str(); op.stream = cur_stream;
         {   // algorithmic HBM bytes of the launch: input once, output once, each residual once, weights once
             const double es = prec == EAGLE_PREC_F16 ? 2 : 4;
-            op.bytes = (double)N * x.h * x.w * cin * es + (double)N * ho * wo * cout * ((out_f32 || prec == EAGLE_PREC_F32) ? 4 : 2) * (am_slot ? 0 : 1) +
+            op.bytes = (double)N * x.h * x.w * cin * es + (double)N * ho * wo * cout * ((out_f32 || prec != EAGLE_PREC_F16) ? 4 : 2) * (am_slot ? 0 : 1) +
                        (r1 ? (double)N * ho * wo * cout * es : 0) + (r2 ? (double)N * ho * wo * cout * es : 0) + (double)ks * ks * cin * cout * es;
         }
         op.run = [L, pr](hipStream_t s) { conv_launch(pr, L, s); };
@@ -419,7 +419,7 @@ static TView build_hrnet(Builder& B, const TView& x_in)
     ys = hr_stage(B, ys, 4, 3, 4, true);
     // fp16 family: sigmoid + per-tile maxima ride in the head convolution's epilogue (no logit tensor in HBM); the exact family
     // keeps the fp32 logits and heat_argmax_kernel
-    ArgmaxPart* const* am = (B.prec == EAGLE_PREC_F16 && !getenv("EAGLE_NO_FUSED_ARGMAX")) ? &B.H->cur_parts : nullptr;
+    ArgmaxPart* const* am = (prec_is_f16_kernels(B.prec) && !getenv("EAGLE_NO_FUSED_ARGMAX")) ? &B.H->cur_parts : nullptr;
     TView logits = B.conv(ys[0], "unnormalized_model.1", "", 1, 0, nullptr, nullptr, 0, nullptr, true, am);
     B.release(ys[0]);
     return logits;
@@ -849,7 +849,7 @@ static void finalize(EagleHandle* h)
     const int B = c.batch;
     h->prec = c.precision;
     h->hr.reset(new Net); h->yo.reset(new Net); h->misc.reset(new Net);
-    const int cin_pad = h->prec == EAGLE_PREC_F16 ? 8 : 4;
+    const int cin_pad = h->prec == EAGLE_PREC_F32 ? 4 : 8;
     h->lb = letterbox_geometry(c.frame_h, c.frame_w, c.det_imgsz);
     // inputs (written by the preprocess kernel)
     Builder Bh{h, h->hr.get(), h->prec, 1e-5, B};
@@ -930,7 +930,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     API_BEGIN
     if (!cfg || !out) fail(EAGLE_E_INVALID, "null argument");
     if (cfg->batch < 1 || cfg->frame_h < 32 || cfg->frame_w < 32) fail(EAGLE_E_INVALID, "bad batch/frame size");
-    if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32) fail(EAGLE_E_INVALID, "bad precision");
+    if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32 && cfg->precision != EAGLE_PREC_F32S) fail(EAGLE_E_INVALID, "bad precision");
     if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -1483,9 +1483,19 @@ int eagle_gather(EagleHandle* h, const EagleFrameResult* local, int n_local, Eag
 // ---- operator-level entry points for the parity tests ---------------------------------------------------------------
 static void to_dev(Net& net, int prec, const float* src, int n, int h, int w, int c, int cpad, TView& v)
 {
-    v.n = n; v.h = h; v.w = w; v.c = cpad; v.cs = cpad; v.off = 0; v.f32 = prec == EAGLE_PREC_F32;
+    v.n = n; v.h = h; v.w = w; v.c = cpad; v.cs = cpad; v.off = 0; v.f32 = prec_tensor_fmt(prec);
     const size_t px = (size_t)n * h * w;
-    if (v.f32) {
+    if (v.f32 == 2) {                                       // [hi x 8][lo x 8] per 8 channels, hi = rn(16 v), lo = rn(16 v - hi)
+        std::vector<_Float16> t(px * cpad * 2, (_Float16)0.f);
+        for (size_t p = 0; p < px; ++p)
+            for (int k = 0; k < c; ++k) {
+                const float sv = src[p * c + k] * 16.0f;
+                const _Float16 hi = (_Float16)sv;
+                t[p * cpad * 2 + (k / 8) * 16 + (k % 8)] = hi;
+                t[p * cpad * 2 + (k / 8) * 16 + 8 + (k % 8)] = (_Float16)(sv - (float)hi);
+            }
+        v.p = net.upload(t.data(), t.size() * 2);
+    } else if (v.f32) {
         std::vector<float> t(px * cpad, 0.f);
         for (size_t p = 0; p < px; ++p) for (int k = 0; k < c; ++k) t[p * cpad + k] = src[p * c + k];
         v.p = net.upload(t.data(), t.size() * 4);
@@ -1498,7 +1508,15 @@ static void to_dev(Net& net, int prec, const float* src, int n, int h, int w, in
 static void from_dev(const TView& v, int c, float* dst)
 {
     const size_t px = (size_t)v.n * v.h * v.w;
-    if (v.f32) {
+    if (v.f32 == 2) {
+        std::vector<_Float16> t(px * v.cs * 2);
+        HIP_CHECK(hipMemcpy(t.data(), v.p, t.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < px; ++p)
+            for (int k = 0; k < c; ++k) {
+                const size_t e = p * v.cs * 2 + (size_t)((v.off + k) / 8) * 16 + (v.off + k) % 8;
+                dst[p * c + k] = ((float)t[e] + (float)t[e + 8]) * 0.0625f;
+            }
+    } else if (v.f32) {
         std::vector<float> t(px * v.cs);
         HIP_CHECK(hipMemcpy(t.data(), v.p, t.size() * 4, hipMemcpyDeviceToHost));
         for (size_t p = 0; p < px; ++p) for (int k = 0; k < c; ++k) dst[p * c + k] = t[p * v.cs + v.off + k];
@@ -1517,20 +1535,20 @@ int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
     Net net;
-    const int g = precision == EAGLE_PREC_F16 ? 8 : 4;
+    const int g = precision == EAGLE_PREC_F32 ? 4 : 8;
     const int cin_pad = cin <= g ? g : (cin + 15) / 16 * 16, cout_pad = (cout + 15) / 16 * 16;
     const int ho = (h + 2 * (ks / 2) - ks) / stride + 1, wo = (w + 2 * (ks / 2) - ks) / stride + 1;
     ConvLaunch L;
     to_dev(net, precision, x, n, h, w, cin, cin_pad, L.x);
     L.cfg = conv_choose(precision, ks, stride, cin_pad, cout_pad, wo, pre_act == ACT_NONE && post_act <= ACT_RELU, r1 && r2);
     if (!conv_supported(precision, L.cfg)) fail(EAGLE_E_NOKERNEL, "no kernel instance ks=%d s=%d kc=%d nt=%d", ks, stride, L.cfg.kc, L.cfg.nt);
-    std::vector<char> tiled(conv_weight_elems(precision, L.cfg) * (precision == EAGLE_PREC_F16 ? 2 : 4));
-    conv_tile_weights(precision, L.cfg, w_hwio, cin, cout, tiled.data());
+    std::vector<char> tiled(conv_weight_elems(precision, L.cfg) * (precision == EAGLE_PREC_F32 ? 4 : 2));
+    conv_tile_weights(precision, L.cfg, w_hwio, cin, cout, tiled.data(), &L.descale);
     L.w = net.upload(tiled.data(), tiled.size());
     std::vector<float> b(cout_pad, 0.f);
     for (int i = 0; i < cout; ++i) b[i] = bias[i];
     L.bias = (const float*)net.upload(b.data(), b.size() * 4);
-    L.y.n = n; L.y.h = ho; L.y.w = wo; L.y.c = cout_pad; L.y.cs = cout_pad; L.y.f32 = precision == EAGLE_PREC_F32;
+    L.y.n = n; L.y.h = ho; L.y.w = wo; L.y.c = cout_pad; L.y.cs = cout_pad; L.y.f32 = prec_tensor_fmt(precision);
     L.y.p = net.get((size_t)n * ho * wo * cout_pad * L.y.esize());
     if (r1) to_dev(net, precision, r1, n, ho, wo, cout, cout_pad, L.r1);
     if (r2) to_dev(net, precision, r2, n, ho, wo, cout, cout_pad, L.r2);
@@ -1567,13 +1585,13 @@ int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, in
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
     Net net;
-    const int cp = precision == EAGLE_PREC_F16 ? 8 : 4;
+    const int cp = precision == EAGLE_PREC_F32 ? 4 : 8;
     const LetterBox lb = letterbox_geometry(h, w, det_imgsz);
     det_hw[0] = lb.out_h; det_hw[1] = lb.out_w;
     if (!kp_out || !det_out) return EAGLE_OK;
     uint8_t* d = (uint8_t*)net.upload(bgr, (size_t)n * h * w * 3);
     TView kp, det;
-    kp.n = n; kp.h = 540; kp.w = 960; kp.c = kp.cs = cp; kp.f32 = precision == EAGLE_PREC_F32;
+    kp.n = n; kp.h = 540; kp.w = 960; kp.c = kp.cs = cp; kp.f32 = prec_tensor_fmt(precision);
     det = kp; det.h = lb.out_h; det.w = lb.out_w;
     kp.p = net.get((size_t)n * 540 * 960 * cp * kp.esize());
     det.p = net.get((size_t)n * lb.out_h * lb.out_w * cp * det.esize());

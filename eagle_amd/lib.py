@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAGLE_HIP_LIB") or os.path.join(_HERE, "libeagle_hip.so")   # override: developer A/B builds only
 
 MAX_DET, N_LANDMARKS, MAX_KP = 300, 57, 87
-PREC_F16, PREC_F32 = 0, 1
+PREC_F16, PREC_F32, PREC_F32S = 0, 1, 2
+PRECISIONS = {"f16": PREC_F16, "f32": PREC_F32, "f32s": PREC_F32S}      # include/eagle.h EAGLE_PREC_*
 DET_VARIANTS = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
 
 

@@ -37,6 +37,9 @@ extern "C" {
 
 #define EAGLE_PREC_F16 0       /* fp16 tensors, fp32 accumulate on v_mfma_f32_16x16x32_f16 (fast path) */
 #define EAGLE_PREC_F32 1       /* fp32 tensors on v_mfma_f32_16x16x4_f32: bit-exact vs the oracle's fmaf chain */
+#define EAGLE_PREC_F32S 2      /* fp32-grade: every tensor value as a (hi, lo) pair of binary16 numbers (4 bytes, 22+ significant bits), products as
+                                  three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi) into an fp32 accumulator: the error of an fp32 summation in
+                                  another order, at 3/16 of the fp32 MFMA's cost per product */
 
 #define EAGLE_DET_N 0
 #define EAGLE_DET_S 1

@@ -6,6 +6,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 F16_TOL = 2e-3  # relative to max|y|: fp16 output rounding (2^-11) + reordered fp32 accumulation
+# Split family (EAGLE_PREC_F32S): operands carry 22+ bits, products hi*hi + hi*lo + lo*hi are accumulated in fp32 in the MFMA's order.
+# Measured on MI355X against float64 (tools/probes/split_mfma_probe.hip): rms error 2.0e-7 .. 6.5e-7 of the output rms for K = 288 .. 3456,
+# i.e. that of the fp32 fmaf chain itself; the bound below is on the largest deviation from the fp32 oracle relative to max|y|.
+F32S_TOL = 4e-6
+
+
+def _split_round(a):
+    """What storing an array in the split format keeps: hi = rn16(16 v), lo = rn16(16 v - hi) -> (hi + lo) / 16."""
+    s = a.astype(np.float32) * np.float32(16)
+    hi = s.astype(np.float16).astype(np.float32)
+    lo = (s - hi).astype(np.float16).astype(np.float32)
+    return (hi + lo) * np.float32(0.0625)
 
 
 def _rand(shape, seed, scale=1.0):
@@ -30,7 +42,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "f32s"])
 def test_conv_parity(case, prec):
     from eagle_amd import lib
     from oracle import prims as P
@@ -46,6 +58,11 @@ def test_conv_parity(case, prec):
         ref = P.conv2d(x, wt, b, stride=st, pre=pre, r1=r1, r2=r2, post=post)
         got = lib.op_conv2d(x, wt, b, st, pre, r1, r2, post, lib.PREC_F32)
         assert np.array_equal(ref, got), f"fp32 conv not bit-exact: max|d|={np.abs(ref - got).max()}"
+    elif prec == "f32s":
+        ref = P.conv2d(x, wt, b, stride=st, pre=pre, r1=r1, r2=r2, post=post)          # the fp32 oracle itself, no emulation
+        got = lib.op_conv2d(x, wt, b, st, pre, r1, r2, post, lib.PREC_F32S)
+        err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+        assert err < F32S_TOL, f"split conv error {err}"
     else:
         q = P.round_f16
         ref = P.conv2d(q(x), q(wt), b, stride=st, pre=pre, r1=None if r1 is None else q(r1),
@@ -116,7 +133,45 @@ def _a_direct_case(cin, cout, shape, res, post, stride):
     assert err < F16_TOL, f"fp16 A-direct conv error {err}"
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("force", ["16,1,0", "16,2,0", "16,3,0", "16,4,0", "32,3,0", "32,4,0", "16,6,3", "32,6,3", "16,4,3", "32,2,3"])
+@pytest.mark.parametrize("cin,cout,ks,stride", [(96, 96, 3, 1), (64, 192, 3, 2), (192, 96, 1, 1)])
+def test_conv_split_variants(force, cin, cout, ks, stride, monkeypatch):
+    """Every (kc, nt, tile) instance class of the split family through EAGLE_CONV_FORCE, on a ragged map with two residuals and ReLU,
+    against the fp32 oracle."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    kc, nt, _ = (int(v) for v in force.split(","))
+    if cout % (16 * nt) or cin % kc or (ks == 1 and kc == 8):
+        pytest.skip("shape does not fit this instance")
+    monkeypatch.setenv("EAGLE_CONV_FORCE", force)
+    n, h, w = 2, 19, 45
+    ho, wo = (h + 2 * (ks // 2) - ks) // stride + 1, (w + 2 * (ks // 2) - ks) // stride + 1
+    x = _rand((n, h, w, cin), 31)
+    wt = _rand((ks, ks, cin, cout), 32, (2.0 / (cin * ks * ks)) ** 0.5)
+    b = _rand((cout,), 33, 0.1)
+    r1, r2 = _rand((n, ho, wo, cout), 34), _rand((n, ho, wo, cout), 35)
+    ref = P.conv2d(x, wt, b, stride=stride, pre=0, r1=r1, r2=r2, post=1)
+    got = lib.op_conv2d(x, wt, b, stride, 0, r1, r2, 1, lib.PREC_F32S)
+    err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < F32S_TOL, f"split conv error {err}"
+
+
+def test_conv_split_small_and_large_magnitudes():
+    """The power-of-two operand scaling keeps the lo parts out of binary16's subnormal range: weights of magnitude 1e-3 and activations of
+    magnitude 1e-2 / 1e+2 give the same relative accuracy as O(1) operands."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    for ws, xs in [(1e-3, 1.0), (1.0, 1e-2), (0.05, 1e2), (30.0, 1.0)]:
+        x = _rand((1, 20, 37, 48), 41, xs)
+        wt = _rand((3, 3, 48, 48), 42, ws)
+        b = np.zeros(48, np.float32)
+        ref = P.conv2d(x, wt, b, stride=1, pre=0, r1=None, r2=None, post=0)
+        got = lib.op_conv2d(x, wt, b, 1, 0, None, None, 0, lib.PREC_F32S)
+        err = np.abs(ref - got).max() / np.abs(ref).max()
+        assert err < F32S_TOL, f"weights x{ws}, activations x{xs}: error {err}"
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16", "f32s"])
 @pytest.mark.parametrize("shape,upshapes", [((2, 27, 31, 48), [(14, 16), (7, 8), (4, 4)]), ((1, 135, 240, 48), [(68, 120), (34, 60), (17, 30)]),
                                             ((3, 34, 60, 192), [(17, 30)]), ((2, 9, 33, 96), [(5, 17), (1, 1)])])
 def test_fuse_sum_parity(prec, shape, upshapes):
@@ -127,14 +182,16 @@ def test_fuse_sum_parity(prec, shape, upshapes):
     n, H, W, c = shape
     base = _rand(shape, 1)
     ups = [_rand((n, h, w, c), 2 + i) for i, (h, w) in enumerate(upshapes)]
-    q = P.round_f16 if prec == "f16" else (lambda a: a)
+    q = P.round_f16 if prec == "f16" else _split_round if prec == "f32s" else (lambda a: a)
     y = q(base)
     for u in ups:
         y = y + P.upsample_bilinear_ac(q(u), H, W)
     ref = np.maximum(y, np.float32(0))
-    got = lib.op_fuse_sum(base, ups, True, lib.PREC_F32 if prec == "f32" else lib.PREC_F16)
+    got = lib.op_fuse_sum(base, ups, True, lib.PRECISIONS[prec])
     if prec == "f32":
         assert np.array_equal(ref, got)
+    elif prec == "f32s":
+        assert np.array_equal(_split_round(ref), got)   # identical fp32 math on the stored (22-bit) operands, one split rounding at the store
     else:
         assert np.array_equal(P.round_f16(ref), got)    # identical fp32 math, one fp16 rounding at the store
 
@@ -148,6 +205,9 @@ def test_preprocess_parity(hw):
     for i in range(2):
         assert np.array_equal(host.preprocess_keypoints(f[i])[0], kp[i])
         assert np.array_equal(host.preprocess_detector(f[i], 640)[0][0], det[i])
+    kps, dets = lib.op_preprocess(f, 640, lib.PREC_F32S)      # the split family stores the same fp32 values to 22+ bits
+    assert np.array_equal(_split_round(kp), kps) and np.array_equal(_split_round(det), dets)
+    assert np.abs(kps - kp).max() <= 2.0 ** -22 * np.abs(kp).max()
 
 
 def _camera_points(seed, noise=0.0, n_out=0):

@@ -8,7 +8,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "f16"
 batches = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8]
 hs, ys = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("n", 0)
 for B in batches:
-    h = lib.Handle(batch=B, precision=lib.PREC_F16 if prec == "f16" else lib.PREC_F32, use_graph=int(os.environ.get('GRAPH', '0')))
+    h = lib.Handle(batch=B, precision=lib.PRECISIONS[prec], use_graph=int(os.environ.get('GRAPH', '0')))
     t = time.time(); weights.load_into(h, [hs, ys]); print(f"B={B} finalize {time.time()-t:.1f}s", flush=True)
     NB = 6
     frames = synth.clip(0, B * NB, distinct=min(B, 4))

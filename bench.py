@@ -30,6 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
+# peak of the convolution family per precision, in ALGORITHMIC TFLOP/s (2 x MAC of the convolution): the split family spends three fp16 MFMA
+# products per algorithmic product (hi*hi + hi*lo + lo*hi), so its roof is a third of the dense fp16 MFMA peak
+PEAK = {"f16": MFMA_PEAK_TFLOPS, "f32": 157.3, "f32s": MFMA_PEAK_TFLOPS / 3.0}
+CONV_KERNEL = {"f16": "conv_f16_ad_kernel / conv_f16_ws_kernel / conv_f16_kernel", "f32": "conv_f32_kernel",
+               "f32s": "conv_f16_kernel<..., SPLIT> family (3 x v_mfma_f32_16x16x32_f16 per K-step)"}
 
 
 def log(msg):
@@ -77,7 +82,8 @@ def main():
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--precision", default="f32s", choices=["f16", "f32", "f32s"],
+                    help="f32s (default): split-precision family, fp32-grade results (records equal the fp32 oracle's); f16: the fast family; f32: the bit-exact family")
     ap.add_argument("--distinct", type=int, default=20, help="distinct synthetic frames generated (tiled to the clip)")
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,7 +124,7 @@ def main():
     hs = weights.make_hrnet_state_dict(0)
     ys = weights.make_yolo_state_dict(a.detector, 0)
     h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
-                   batch=B, precision=lib.PREC_F16 if a.precision == "f16" else lib.PREC_F32,
+                   batch=B, precision=lib.PRECISIONS[a.precision],
                    use_graph=1 if a.graph else 0)
     weights.load_into(h, [hs, ys])
     log(f"rank {rank}: handle ready (batch {B})")
@@ -232,7 +238,7 @@ def main():
         if name.startswith("conv ") and ms > 0:
             us = ms * 1e3 / launches
             conv_rows.append({"layer": name[5:], "launches_per_step": launches // prof_steps, "avg_us": round(us, 2), "ms_per_step": round(ms / prof_steps, 3),
-                              "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "frac_mfma": round(flop / (ms * 1e-3) / 1e12 / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
+                              "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "frac_mfma": round(flop / (ms * 1e-3) / 1e12 / PEAK[a.precision], 4),
                               "GBps_algorithmic": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_hbm_6p3TBps": round(nbytes / (ms * 1e-3) / 1e9 / 6300.0, 4)})
             continue
         if nbytes > 0 and ms > 0:
@@ -273,13 +279,13 @@ def main():
             "metric": f"frames/sec end-to-end (detect+keypoint+homography) @{a.width}x{a.height}",
             "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if a.precision == "f16" else "f32", "data": f"synthetic ({len(base)} distinct generated frames per rank tiled to {n_local}; seeded synthetic weights)",
+            "dtype": {"f16": "f16", "f32": "f32", "f32s": "f32 (split: hi/lo binary16 pairs, 3 x fp16 MFMA per product, fp32 accumulate)"}[a.precision], "data": f"synthetic ({len(base)} distinct generated frames per rank tiled to {n_local}; seeded synthetic weights)",
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}",
                        "gather": "none" if world == 1 else gather_used, "hip_graph": bool(a.graph)},
-            "roofline": {"bound": "mfma", "kernel": f"conv_f16_kernel / conv_f16_ws_kernel (all {n_conv // prof_steps} convolution launches of a step)" if a.precision == "f16" else "conv_f32_kernel",
-                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3, "unit": "TFLOP/s",
-                         "frac": round(achieved / (MFMA_PEAK_TFLOPS if a.precision == "f16" else 157.3), 4),
+            "roofline": {"bound": "mfma", "kernel": f"{CONV_KERNEL[a.precision]} (all {n_conv // prof_steps} convolution launches of a step)",
+                         "achieved": round(achieved, 2), "peak": round(PEAK[a.precision], 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK[a.precision], 4),
                          "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
                          "conv_ms_per_step": round(conv_ms / prof_steps, 3),
                          "algorithmic_bytes_per_launch": round(conv_bytes / max(n_conv, 1)),

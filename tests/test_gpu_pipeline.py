@@ -349,12 +349,16 @@ def _near_int(v, tol=1e-3):
     return abs(v - round(v)) <= tol
 
 
-def _f32s_record_parity(rec, oref, aux, tag, frame_hw):
+def _f32s_record_parity(rec, oref, aux, tag, frame_hw, conf_tol=5e-6, box_tol=2e-3, score_tol=5e-6):
     """One frame of the split family against the fp32 oracle (OracleModel(backend="c"), the one pinned to the reference) — NOT an emulation
     of the family's own rounding.  north_star's contract: integers identical, floats within 1e-3 relative; what is asserted here is much
     tighter: every integer field identical, floats to a few 1e-6.  The only admitted integer differences are the two SURVEY §0 names
     — a float that sits within 1e-3 of an integer before truncation, and an arg-max between two heat-map values closer than 2e-6 — and each
-    occurrence is counted and returned so that the summary line shows them."""
+    occurrence is counted and returned so that the summary line shows them.
+    Float tolerances are set from the spread between the oracle's OWN two fp32 backends (exact fmaf chain vs torch / oneDNN, i.e. two legitimate
+    fp32 summation orders; tools/probes/fp32_order_noise.py): cfg 2 — confidences 2.4e-6, heat-map scores 2.4e-7, logits 8.8e-7 relative, and
+    one swapped pair of detection ids; cfg 3 (yolov8l, 103 convolutions deep) — confidences 2.0e-5, boxes 5.3e-3 px.  conf_tol / box_tol are
+    2x those; the family's measured deviations (printed) stay below the fp32 spread itself."""
     from eagle_amd import records
     from eagle_amd.pitch import INTERSECTION_TO_PITCH_POINTS
     from oracle import prims as P
@@ -367,7 +371,7 @@ def _f32s_record_parity(rec, oref, aux, tag, frame_hw):
             assert sig[gi, c] >= aux["hm_score"][c] * (1 - 2e-6), f"{tag} ch {c}: arg-max {gi} vs {oi} is not a near-tie ({sig[gi, c]} vs {aux['hm_score'][c]})"
             out["hm_tie"] += 1
     sdev = float(np.abs(rec["hm_score"].astype(np.float64) - aux["hm_score"]).max())
-    assert sdev <= 5e-6, f"{tag}: heat-map score moved by {sdev}"
+    assert sdev <= score_tol, f"{tag}: heat-map score moved by {sdev}"
     out["max_score_dev"] = sdev
     # (2) key-points: pixels, labels, synthesised points
     kp = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"])) for k in rec["kp"][: int(rec["n_kp"])] if not k["synthesized"]}
@@ -394,12 +398,12 @@ def _f32s_record_parity(rec, oref, aux, tag, frame_hw):
         # deviation (a few 1e-7), its neighbour: that swap of ids is the "confidence near-tie" the summary counts
         def fits(j):
             gj = rec["det"][j]
-            return (int(gj["cls"]) == int(d[5]) and abs(float(gj["conf"]) - float(d[4])) <= 5e-6 and
-                    float(np.abs(np.array([float(gj[k]) for k in ("x1", "y1", "x2", "y2")]) - d[:4]).max()) <= 2e-3)
+            return (int(gj["cls"]) == int(d[5]) and abs(float(gj["conf"]) - float(d[4])) <= conf_tol and
+                    float(np.abs(np.array([float(gj[k]) for k in ("x1", "y1", "x2", "y2")]) - d[:4]).max()) <= box_tol)
         js = [j for j in (i, i - 1, i + 1) if 0 <= j < n and fits(j)]
         assert js, f"{tag}: detection {i} (cls {d[5]}, conf {d[4]}, box {d[:4]}) has no counterpart at ids {i - 1}..{i + 1}: GPU has {rec['det'][i]}"
         if js[0] != i:
-            assert abs(float(dets[js[0]][4]) - float(d[4])) <= 1e-5, f"{tag}: detections {i} / {js[0]} swapped without a confidence near-tie"
+            assert abs(float(dets[js[0]][4]) - float(d[4])) <= 2 * conf_tol, f"{tag}: detections {i} / {js[0]} swapped without a confidence near-tie"
             out["conf_tie"] += 1
             continue
         g = rec["det"][i]
@@ -466,7 +470,11 @@ def test_f32s_family_equals_fp32_oracle_random_head(state_dicts, frames, oracle_
     cm.handle.close()
     tot = [_f32s_record_parity(recs[i], oref, aux, f"f32s random head frame {i}", (720, 1280)) for i, (oref, aux) in enumerate(oracle_steps)]
     print("f32s parity (random head):", tot)
-    assert sum(t["hm_tie"] for t in tot) <= 2 and sum(t["near_int_box"] + t["conf_tie"] for t in tot) <= 2, tot
+    # The random-weight detector reports 240 - 300 boxes per frame with confidences ~1e-3 apart, so a few neighbouring ids swap under ANY
+    # change of fp32 summation order (the oracle's own two backends swap a pair on frame 0): each swap is verified as a near-tie above and
+    # counted; test_f32s_ids_identical_with_a_sparse_detector is the same comparison with a realistic number of detections.
+    assert sum(t["hm_tie"] for t in tot) <= 2 and sum(t["near_int_box"] for t in tot) <= 2, tot
+    assert sum(t["conf_tie"] for t in tot) <= 0.02 * sum(t["dets"] for t in tot), tot
     assert sum(t["dets"] for t in tot) > 20
 
 
@@ -486,10 +494,13 @@ def test_f32s_family_equals_fp32_oracle_peaked_head_cfg2(state_dicts):
     tot = []
     for i, f in enumerate(frames):
         oref, aux = ora.step(f, i)
-        tot.append(_f32s_record_parity(recs[i], oref, aux, f"f32s peaked cfg2 frame {i}", (720, 1280)))
+        # the matched-filter head multiplies backbone deviations by ALPHA / |patch|^2 (make_peaked_head.py): peak VALUES move ~20x more than on
+        # the random head, peak positions do not move
+        tot.append(_f32s_record_parity(recs[i], oref, aux, f"f32s peaked cfg2 frame {i}", (720, 1280), score_tol=3e-5))
     print("f32s parity (peaked head, cfg2):", tot)
     assert sum(bool(t["h_identical"]) for t in tot) >= 5, tot
-    assert sum(t["hm_tie"] + t["near_int_box"] + t["conf_tie"] for t in tot) <= 2, tot
+    assert sum(t["hm_tie"] + t["near_int_box"] for t in tot) <= 2, tot
+    assert sum(t["conf_tie"] for t in tot) <= 0.02 * sum(t["dets"] for t in tot), tot
 
 
 def test_f32s_family_equals_fp32_oracle_cfg3():
@@ -504,9 +515,35 @@ def test_f32s_family_equals_fp32_oracle_cfg3():
     rec = cm.process_records(frame[None])[0]
     cm.handle.close()
     oref, aux = pipeline.OracleModel(hs2, yl, variant="l", imgsz=960, backend="c").step(frame, 0)
-    t = _f32s_record_parity(rec, oref, aux, "f32s cfg3", (1080, 1920))
+    t = _f32s_record_parity(rec, oref, aux, "f32s cfg3", (1080, 1920), conf_tol=4e-5, box_tol=1e-2, score_tol=3e-5)
     print("f32s parity (cfg3):", t)
-    assert t["h_identical"] and t["hm_tie"] + t["near_int_box"] + t["conf_tie"] <= 1, t
+    assert t["h_identical"] and t["hm_tie"] + t["near_int_box"] <= 1 and t["conf_tie"] <= 0.04 * t["dets"], t
+
+
+def test_f32s_ids_identical_with_a_sparse_detector(state_dicts):
+    """The id contract (detection index in descending-confidence order, cm.py:598-616) with a realistic number of detections: the class
+    biases of the synthetic detector lowered until a frame keeps a few dozen boxes, confidences then lie ~1e-2 apart and every id, class,
+    integer box and pitch integer must equal the fp32 oracle's with NO admitted exception."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    from oracle import pipeline
+    hs, ys = state_dicts
+    hs2, g = _peaked_state_dict(hs)
+    ys2 = dict(ys)
+    for l in range(3):
+        ys2[f"model.22.cv3.{l}.2.bias"] = (ys[f"model.22.cv3.{l}.2.bias"] - np.float32(1.25)).astype(np.float32)
+    frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 9), synth.frame(2, 5)])
+    cm = CoordinateModel(precision="f32s", batch=3, hrnet_state_dict=hs2, detector_state_dict=ys2)
+    recs = cm.process_records(frames)
+    cm.handle.close()
+    ora = pipeline.OracleModel(hs2, ys2, backend="c")
+    tot = []
+    for i, f in enumerate(frames):
+        oref, aux = ora.step(f, i)
+        tot.append(_f32s_record_parity(recs[i], oref, aux, f"f32s sparse detector frame {i}", (720, 1280), score_tol=3e-5))
+    print("f32s parity (sparse detector):", tot)
+    assert all(3 <= t["dets"] <= 120 for t in tot), [t["dets"] for t in tot]
+    assert sum(t["hm_tie"] + t["near_int_box"] + t["conf_tie"] for t in tot) == 0, tot
 
 
 def test_f32s_batch_and_position_invariance(state_dicts, frames):

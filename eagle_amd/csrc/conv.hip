@@ -49,6 +49,10 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
         const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 2 + 16);        // output transpose, one strip per wave
         return conv_ws(c) ? operands + strips + 16 : std::max(operands + 16, strips);
     }
+    if (precision == EAGLE_PREC_F32S && conv_ad(c)) {      // same halo ring as the fp16 kernel (16 logical channels = the 96-byte record), strips of 16 pixels x 48 channels x 4 bytes
+        const int pgn = conv_ad_wide(c) ? 1 : 2, slabs = (((4 * pgn + 2) * 34 * 96 + 1023) / 1024 + 3) / 4 * 4;
+        return (size_t)2 * slabs * 1024 + 4 * 16 * 208;
+    }
     if (precision == EAGLE_PREC_F32S) {                    // hi and lo fragment blocks per K-step; 2 * kc fp16 values per staged pixel; 4-byte outputs
         const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 2 * 4 * bn * 16 + (size_t)hh * hw * f16_ps(2 * c.kc);
         const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 4 + 16);
@@ -69,7 +73,9 @@ int conv_tiles_per_frame(const ConvConfig& c, int ho, int wo)
 // kernels in conv_ad_s1.hip / conv_ad_s2.hip.
 static const Inst g_ad_inst[] = {
     // A-direct 3x3 kernels (variant 8: BN = 192, tile 4 x 32; 9: BN = 96, tile 8 x 32; 10 / 11: the same for stride 2); kc = 32
-    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, nullptr}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, nullptr}, {EAGLE_PREC_F16, 3, 2, 32, 12, 10, nullptr}, {EAGLE_PREC_F16, 3, 2, 32, 6, 11, nullptr}};
+    {EAGLE_PREC_F16, 3, 1, 32, 12, 8, nullptr}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, nullptr}, {EAGLE_PREC_F16, 3, 2, 32, 12, 10, nullptr}, {EAGLE_PREC_F16, 3, 2, 32, 6, 11, nullptr},
+    // split family: chunks of 16 logical channels (conv_ad_split.inc)
+    {EAGLE_PREC_F32S, 3, 1, 16, 12, 8, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 9, nullptr}};
 
 const Inst* conv_inst_part(int part, int* n)
 {
@@ -119,6 +125,12 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
             ConvConfig q = c;
             if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 && find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024)
                 return q;
+        }
+        static const bool sad_on = !(getenv("EAGLE_CONV_AD") && atoi(getenv("EAGLE_CONV_AD")) == 0);
+        if (sad_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 96 == 0) {      // A-direct, split form (three 16-channel chunks per loop body)
+            ConvConfig q = c; q.kc = 16;
+            if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 8; } else { q.nt = 6; q.variant = 9; }
+            return q;
         }
         static const int skcs[] = {32, 16, 8};
         long best = -1;
@@ -189,6 +201,7 @@ size_t conv_weight_elems(int precision, const ConvConfig& c)
     if (precision == EAGLE_PREC_F16 && conv_ad(c) && c.stride == 2) return (size_t)(c.cout_pad / (c.nt * 16)) * (4 * c.cin / 32) * 16 * (c.nt * 16) * 8;
     const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc;
     if (precision == EAGLE_PREC_F16) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 4 * bn * 8;
+    if (precision == EAGLE_PREC_F32S && conv_ad(c)) return (size_t)nblk * (c.cin / 16) * 14 * 4 * bn * 8;   // 14 K-steps per 16-channel chunk
     if (precision == EAGLE_PREC_F32S) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 2 * 4 * bn * 8;      // fp16 elements: a hi and a lo block per K-step
     return (size_t)nblk * nch * c.ks * c.ks * (c.kc / 4) * 4 * bn;
 }
@@ -209,8 +222,26 @@ void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int c
         const int sw = 15 - e;                                             // scaled maximum in [2^14, 2^15)
         const float scale = std::ldexp(1.0f, sw);
         if (descale) *descale = std::ldexp(1.0f, -(sw + 4));
-        const int G = c.kc / 8, NGR = taps * G, NI = f16_ni(c.ks, c.kc);
         _Float16* d = (_Float16*)dst;
+        if (conv_ad(c)) {
+            // A-direct form: [Cout block][16-channel chunk][K-step 0..13][q][BN][8].  K-steps 0..8 = taps, lane groups (hi g0, hi g1, hi g0, hi g1):
+            // against the record slots (hi g0, hi g1, lo g0, lo g1) that is hi*hi + hi*lo.  K-steps 9..13 = tap pairs (0|1, 2|3, 4|5, 6|7, 8|-),
+            // lane groups (lo g0, lo g1 at the first tap | lo g0, lo g1 at the second): lo*hi.
+            for (int b = 0; b < nblk; ++b)
+                for (int ch = 0; ch < c.cin / 16; ++ch)
+                    for (int k = 0; k < 14; ++k)
+                        for (int qq = 0; qq < 4; ++qq)
+                            for (int nn = 0; nn < bn; ++nn)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int tap = k < 9 ? k : 2 * (k - 9) + (qq >> 1);
+                                    float v = 0.f;
+                                    if (tap < 9) v = W(tap, ch * 16 + (qq & 1) * 8 + j, b * bn + nn) * scale;
+                                    const _Float16 hi = (_Float16)v;
+                                    *d++ = k < 9 ? hi : (_Float16)(v - (float)hi);
+                                }
+            return;
+        }
+        const int G = c.kc / 8, NGR = taps * G, NI = f16_ni(c.ks, c.kc);
         for (int b = 0; b < nblk; ++b)
             for (int ch = 0; ch < nch; ++ch)
                 for (int i = 0; i < NI; ++i)
@@ -317,8 +348,9 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
-        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != 32 || c.ks != 3 || c.stride != (c.variant >= 10 ? 2 : 1))
-            fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32, fp16 output, pre_act none, post_act in {none, ReLU}");
+        const bool split = precision == EAGLE_PREC_F32S;
+        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != (c.variant >= 10 ? 2 : 1) || (split && (c.stride != 1 || c.cin % 48)))
+            fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32 (16 in the split family, stride 1 only), 2-byte / split output, pre_act none, post_act in {none, ReLU}");
         if (c.stride == 2) a.nchunks = 4 * c.cin / 32;      // chunks of the space-to-depth image
         const int thh = conv_ad_wide(c) ? 4 : 8;
         a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + thh - 1) / thh;
@@ -327,7 +359,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)

@@ -1,0 +1,23 @@
+// A-direct convolution kernels of the split-precision family (see conv_ad_split.inc; own translation unit for build time).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "dmath.h"
+#include "conv_internal.h"
+
+namespace eagle {
+
+#include "conv_kernels.inc"
+#include "conv_ad_split.inc"
+
+ConvKernel conv_ad_split_kernel(bool wide, int n_res)
+{
+    static const ConvKernel fn[2][3] = {
+        {conv_split_ad_kernel<2, 2, 0>, conv_split_ad_kernel<2, 2, 1>, conv_split_ad_kernel<2, 2, 2>},
+        {conv_split_ad_kernel<4, 1, 0>, conv_split_ad_kernel<4, 1, 1>, conv_split_ad_kernel<4, 1, 2>}};
+    return fn[wide ? 1 : 0][n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
+}
+
+}  // namespace eagle

@@ -36,5 +36,6 @@ const Inst* conv_inst_split0(int* n); const Inst* conv_inst_split1(int* n); cons
 // the A-direct kernel instance for (cout_groups x pixel_groups, number of residual operands): wide = 4 x 1 (BN 192), otherwise 2 x 2 (BN 96)
 ConvKernel conv_ad_kernel_s1(bool wide, int n_res);
 ConvKernel conv_ad_kernel_s2(bool wide, int n_res);
+ConvKernel conv_ad_split_kernel(bool wide, int n_res);      // EAGLE_PREC_F32S form (conv_ad_split.inc), stride 1
 
 }  // namespace eagle

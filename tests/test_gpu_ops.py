@@ -156,6 +156,28 @@ def test_conv_split_variants(force, cin, cout, ks, stride, monkeypatch):
     assert err < F32S_TOL, f"split conv error {err}"
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 96), (192, 192), (48, 192), (384, 384), (144, 96)])
+@pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (5, 17, 30), (1, 68, 120)])
+@pytest.mark.parametrize("res,post", [(True, 1), (False, 1), (False, 0), (2, 1)])
+def test_conv_split_a_direct(cin, cout, shape, res, post):
+    """The A-direct kernels of the split family (conv_ad_split.inc; conv_choose picks them for 3x3 stride-1 layers with Cin = 48 k and
+    Cout = 96 k) against the fp32 oracle: ragged maps, several items per workgroup and Cout blocks, 0 / 1 / 2 residual operands."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    if shape[1] * shape[2] > 4000 and (cin > 96 or not res):
+        pytest.skip("large map: one representative case")
+    n, h, w = shape
+    x = _rand((n, h, w, cin), 51)
+    wt = _rand((3, 3, cin, cout), 52, (2.0 / (cin * 9)) ** 0.5)
+    b = _rand((cout,), 53, 0.1)
+    r1 = _rand((n, h, w, cout), 54) if res else None
+    r2 = _rand((n, h, w, cout), 55) if res == 2 else None
+    ref = P.conv2d(x, wt, b, stride=1, pre=0, r1=r1, r2=r2, post=post)
+    got = lib.op_conv2d(x, wt, b, 1, 0, r1, r2, post, lib.PREC_F32S)
+    err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < F32S_TOL, f"split A-direct conv error {err}"
+
+
 def test_conv_split_small_and_large_magnitudes():
     """The power-of-two operand scaling keeps the lo parts out of binary16's subnormal range: weights of magnitude 1e-3 and activations of
     magnitude 1e-2 / 1e+2 give the same relative accuracy as O(1) operands."""

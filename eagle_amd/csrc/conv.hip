@@ -101,6 +101,9 @@ struct Tuned { int ks, s, cin, cout, wo, kc, nt, wx, variant; };
 static const Tuned g_tuned[] = {
 #include "conv_tuned.inc"
     {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+static const Tuned g_tuned_split[] = {       // EAGLE_PREC_F32S (tools/autotune_split.py); rows of one shape are ordered best first
+#include "conv_tuned_split.inc"
+    {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue, bool second_residual)
 {
@@ -127,6 +130,14 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
                 return q;
         }
         static const bool sad_on = !(getenv("EAGLE_CONV_AD") && atoi(getenv("EAGLE_CONV_AD")) == 0);
+        static const bool tuned_on = !(getenv("EAGLE_CONV_TUNED") && atoi(getenv("EAGLE_CONV_TUNED")) == 0);
+        if (tuned_on)
+            for (const Tuned& t : g_tuned_split)
+                if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
+                    ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = t.variant;
+                    if (conv_ad(q) && !(sad_on && plain_epilogue && cin_pad % 48 == 0)) continue;       // the A-direct kernels: ReLU / none after at most two residual adds, three chunks per loop body
+                    if (find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
+                }
         if (sad_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 96 == 0) {      // A-direct, split form (three 16-channel chunks per loop body)
             ConvConfig q = c; q.kc = 16;
             if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 8; } else { q.nt = 6; q.variant = 9; }

@@ -10,11 +10,14 @@ Multi-GPU (driver launches one rank per GPU through torch.distributed.run): fram
 weights replicated, no data-path collective; ONE all-gather of the fixed-size records at the end (inside the timed
 region); value = total frames of all ranks / max-over-ranks time  ("scaling": "weak").
 
-``value`` = frames/s with the clip already resident in HBM (the contract's definition).  The same line also carries
-``pcie_inclusive`` (SURVEY §8d's definition: the frames start in HOST memory; measured from pageable memory through the library's
-pinned ring and from pinned memory), ``exact_family`` (the fp32 kernel family, whose records are bit-identical to the oracle's: a
-short run of the same path), ``roofline`` (MFMA, the convolution family) and ``roofline_hbm`` (the bandwidth-bound kernels K1/K4/K5/K6/K7
-against 8 TB/s, from HIP events on their launch streams and their algorithmic bytes).
+Default family = EAGLE_PREC_F32S ("f32s": fp32-grade results — records equal the fp32 oracle's, tests/test_gpu_pipeline.py::test_f32s_* —
+computed as three fp16 MFMAs per product over (hi, lo) binary16 tensors).  ``value`` = frames/s with the clip already resident in HBM (the
+measurement contract's definition).  The same line also carries ``pcie_inclusive`` (SURVEY §8d's definition: the frames start in HOST
+memory; pageable memory through the library's pinned ring, and pinned memory), ``fast_family`` (the fp16 family on the same clip),
+``exact_family`` (the bit-exact fp32 family on the same clip), ``parity_counters`` (integer-field differences of both faster families against
+the exact family's records on the distinct frames of the clip — GPU against GPU, the exact family being the one that equals the oracle bit
+for bit), ``cfg3`` (BASELINE configs[2]: 1920x1080, yolov8l@960, a 200-frame run of both families), ``roofline`` (MFMA, the convolution
+family) and ``roofline_hbm`` (the bandwidth-bound kernels against 8 TB/s, HIP events on their launch streams / algorithmic bytes).
 
 Prints ONE JSON line on rank 0.  The CPU oracle appears here only as the timed ``cpu_baseline`` leg.  At N = 1 torch is not imported
 before the GPU work (the library has its own streams and synchronises its calls itself)."""
@@ -91,7 +94,9 @@ def main():
     ap.add_argument("--host-frames", action="store_true", help="(kept for compatibility: the PCIe-inclusive path is always timed at N = 1)")
     ap.add_argument("--all-layers", action="store_true", help="roofline_conv_layers lists every convolution layer shape instead of the ten heaviest")
     ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / exact_family / roofline_hbm (profiling runs)")
-    ap.add_argument("--exact-frames", type=int, default=100, help="frames of the fp32 exact-family run")
+    ap.add_argument("--exact-frames", type=int, default=1000, help="frames of the fp32 exact-family run (0: skip)")
+    ap.add_argument("--fast-frames", type=int, default=1000, help="frames of the fp16 fast-family run (0: skip)")
+    ap.add_argument("--cfg3-frames", type=int, default=200, help="frames of the configs[2] run (1920x1080, yolov8l@960; 0: skip)")
     ap.add_argument("--cadence", type=int, default=0, metavar="FPS", help="also time the reference's default cadence on the same clip: get_coordinates(frames, FPS, num_homography=1, "
                     "num_keypoint_detection=3) = HRNet every int(FPS/3)-th frame, optical-flow propagation in between (stateful; reported as reference_cadence, never as value)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
@@ -246,33 +251,85 @@ def main():
             hbm_rows.append({"kernel": name, "launches_per_step": launches // prof_steps, "bytes_algorithmic_per_step": round(nbytes / prof_steps),
                              "avg_us": round(ms * 1e3 / launches, 2), "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)})
 
-    exact = None
-    if extras and a.precision == "f16" and a.exact_frames > 0:
-        # the exact family (fp32 tensors, v_mfma_f32_16x16x4_f32 fmaf chains): the kernels whose records equal the oracle's bit for bit
-        Be = min(B, 25)
-        ne = max(Be, a.exact_frames // Be * Be)
-        he = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz, batch=Be, precision=lib.PREC_F32)
-        weights.load_into(he, [hs, ys])
-        oe = np.zeros(ne, lib.RESULT_DTYPE)
-        he.process_device(d_clip, Be, oe[:Be])
+    def family_run(prec, nframes, Bf, d_frames, hw=(a.height, a.width), det=a.detector, imgsz=a.imgsz, sd=None, want_records=0):
+        """A second handle of another precision family on frames that are already resident: frames/s (K steps of Bf in one call), the
+        convolution family's HIP-event roofline, optionally the records of the first `want_records` frames."""
+        hf = lib.Handle(device=dev_index, frame_h=hw[0], frame_w=hw[1], det_variant=det, det_imgsz=imgsz, batch=Bf, precision=lib.PRECISIONS[prec])
+        weights.load_into(hf, sd or [hs, ys])
+        nf = max(Bf, nframes // Bf * Bf)
+        of = np.zeros(nf, lib.RESULT_DTYPE)
+        hf.process_device(d_frames, min(2 * Bf, nf), of[:min(2 * Bf, nf)])
         t1 = time.perf_counter()
-        he.process_device(d_clip, ne, oe)
-        dte = time.perf_counter() - t1
-        ems, eflop, enc, _, _ = profile(he, d_clip, Be, 1)
-        he.close()
-        each = eflop / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
-        exact = {"dtype": "f32", "value": round(ne / dte, 2), "unit": "frames/s", "frames": ne, "frames_per_step": Be,
-                 "roofline": {"bound": "mfma", "kernel": "conv_f32_kernel", "achieved": round(each, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(each / 157.3, 4)},
-                 "note": "same path and clip with EAGLE_PREC_F32: records bit-identical to the CPU oracle (tests/test_gpu_pipeline.py::test_f32_path_identical_to_oracle)"}
-        log(f"exact family (fp32): {exact['value']} frames/s, conv {each:.1f} TFLOP/s")
+        hf.process_device(d_frames, nf, of)
+        dtf = time.perf_counter() - t1
+        fms, fflop, fnc, _, fsteps = profile(hf, d_frames, Bf, 1)
+        hf.close()
+        ach = fflop / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
+        r = {"dtype": prec, "value": round(nf / dtf, 2), "unit": "frames/s", "frames": nf, "frames_per_step": Bf,
+             "roofline": {"bound": "mfma", "kernel": CONV_KERNEL[prec], "achieved": round(ach, 2), "peak": round(PEAK[prec], 1), "unit": "TFLOP/s",
+                          "frac": round(ach / PEAK[prec], 4), "conv_ms_per_step": round(fms / fsteps, 3), "flop_per_frame": fflop / (fsteps * Bf)}}
+        return r, of[:want_records].copy()
+
+    def int_field_diffs(rec, ref):
+        """Integer-field differences of two record arrays of the same frames (per-field counts over all frames)."""
+        c = dict(frames=len(ref), hm_idx=0, n_kp=0, kp_pixels=0, n_det=0, det_cls=0, det_int_box=0, det_pitch_int=0, H_valid=0, dets_compared=0)
+        for g, o in zip(rec, ref):
+            c["hm_idx"] += int((g["hm_idx"] != o["hm_idx"]).sum())
+            c["H_valid"] += int(g["H_valid"] != o["H_valid"])
+            if g["n_kp"] != o["n_kp"]:
+                c["n_kp"] += 1
+            else:
+                k = int(o["n_kp"])
+                c["kp_pixels"] += int(((g["kp"]["x"][:k] != o["kp"]["x"][:k]) | (g["kp"]["y"][:k] != o["kp"]["y"][:k]) | (g["kp"]["label"][:k] != o["kp"]["label"][:k])).sum())
+            if g["n_det"] != o["n_det"]:
+                c["n_det"] += 1
+                continue
+            k = int(o["n_det"])
+            c["dets_compared"] += k
+            c["det_cls"] += int((g["det"]["cls"][:k] != o["det"]["cls"][:k]).sum())
+            c["det_int_box"] += int(np.any([g["det"][f][:k] != o["det"][f][:k] for f in ("bx1", "by1", "bx2", "by2")], axis=0).sum())
+            c["det_pitch_int"] += int(((g["det"]["pitch_x"][:k] != o["det"]["pitch_x"][:k]) | (g["det"]["pitch_y"][:k] != o["det"]["pitch_y"][:k])).sum())
+        return c
+
+    exact = fast = parity = cfg3 = None
+    nd = len(base)
+    if extras and a.exact_frames > 0 and a.precision != "f32":
+        # the exact family (fp32 tensors, v_mfma_f32_16x16x4_f32 fmaf chains): the kernels whose records equal the oracle's bit for bit
+        exact, rec_exact = family_run("f32", a.exact_frames, B, d_clip, want_records=nd)
+        exact["note"] = "same path and clip with EAGLE_PREC_F32: records bit-identical to the CPU oracle (tests/test_gpu_pipeline.py::test_f32_path_identical_to_oracle)"
+        log(f"exact family (fp32): {exact['value']} frames/s, conv {exact['roofline']['achieved']:.1f} TFLOP/s")
+        parity = {"reference": "records of the exact (fp32, oracle-identical) family on the same frames", "frames": nd,
+                  a.precision: int_field_diffs(out[:nd], rec_exact)}
+    if extras and a.fast_frames > 0 and a.precision != "f16":
+        fast, rec_fast = family_run("f16", a.fast_frames, B, d_clip, want_records=nd)
+        fast["note"] = "fp16 tensors, one fp16 MFMA per product: integer outputs are NOT guaranteed equal to the fp32 path's (see parity_counters); reported for reference, never as value"
+        log(f"fast family (fp16): {fast['value']} frames/s, conv {fast['roofline']['achieved']:.1f} TFLOP/s")
+        if parity is not None:
+            parity["f16"] = int_field_diffs(rec_fast, rec_exact)
+    if parity is not None:
+        log(f"parity counters vs the exact family: {json.dumps(parity)}")
+    if extras and a.cfg3_frames > 0 and (a.height, a.width, a.detector) == (720, 1280, "n"):
+        # BASELINE.json configs[2]: 1920x1080 frames, the large detector at imgsz 960 (544.3 GFLOP per frame)
+        B3 = 25
+        n3 = max(B3, a.cfg3_frames // B3 * B3)
+        yl = weights.make_yolo_state_dict("l", 0)
+        base3 = synth.clip(seed=0, n=10, h=1080, w=1920)
+        clip3 = np.concatenate([base3] * (-(-n3 // len(base3))))[:n3]
+        d3 = h.upload(clip3)
+        cfg3 = {"workload": f"{n3}-frame 1920x1080 synthetic clip, yolov8l@960 + HRNet-W48 keypoints + RANSAC homography", "frames_per_step": B3}
+        for pr in (a.precision, "f16") if a.precision != "f16" else ("f16",):
+            r3, _ = family_run(pr, n3, B3, d3, hw=(1080, 1920), det="l", imgsz=960, sd=[hs, yl])
+            cfg3[pr] = r3
+            log(f"cfg3 {pr}: {r3['value']} frames/s, conv {r3['roofline']['achieved']:.1f} TFLOP/s")
+        h.free(d3)
 
     traffic = traffic_src = None
-    tf = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
+    tf = os.path.join(ROOT, "profiles", "conv_hbm_traffic.json" if a.precision == "f16" else f"conv_hbm_traffic_{a.precision}.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
     if os.path.exists(tf):
         tj = json.load(open(tf))
         if tj.get("batch") == B and tj.get("detector") == a.detector and tj.get("precision") == a.precision:
             traffic = tj["conv_family"]["hbm_bytes_per_launch"]
-            traffic_src = f"NOT measured in this run: read from profiles/conv_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build {tj.get('build', '?')}; the library's streams run concurrently in those passes, so kernels of other streams that overlap a convolution are counted into it: an upper bound)"
+            traffic_src = f"NOT measured in this run: read from profiles/{os.path.basename(tf)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build {tj.get('build', '?')}; the library's streams run concurrently in those passes, so kernels of other streams that overlap a convolution are counted into it: an upper bound)"
     res = None
     if rank == 0:
         res = {
@@ -296,8 +353,14 @@ def main():
             res["roofline_hbm"] = hbm_rows
         if conv_rows:      # the ten convolution layer shapes that take the most time, each against BOTH roofs (MFMA peak; 6.3 TB/s achievable HBM)
             res["roofline_conv_layers"] = sorted(conv_rows, key=lambda r: -r["ms_per_step"])[:(len(conv_rows) if a.all_layers else 10)]
+        if fast is not None:
+            res["fast_family"] = fast
         if exact is not None:
             res["exact_family"] = exact
+        if parity is not None:
+            res["parity_counters"] = parity
+        if cfg3 is not None:
+            res["cfg3"] = cfg3
         if cadence is not None:
             res["reference_cadence"] = cadence
         if pcie is not None:

@@ -17,11 +17,11 @@ def load(d, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 _lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "eagle_amd", "libeagle_hip.so")
-out = {"build": "libeagle_hip.so md5 " + hashlib.md5(open(_lib, "rb").read()).hexdigest()[:12] if os.path.exists(_lib) else "?", "batch": 50, "detector": "n", "precision": "f16", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + " ".join(sys.argv[4:]),
+out = {"build": "libeagle_hip.so md5 " + hashlib.md5(open(_lib, "rb").read()).hexdigest()[:12] if os.path.exists(_lib) else "?", "batch": 50, "detector": "n", "precision": (sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "f32s"), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + " ".join(sys.argv[4:]),
        "corrections": "bytes = KiB*1024; FETCH_SIZE doubled (gfx950 under-report of wide coalesced reads)", "kernels": {}}
 tf = tw = n = 0
 for k in fetch:
-    if "conv_f16" not in k and "conv_f32_kernel" not in k:
+    if "conv_f16" not in k and "conv_f32_kernel" not in k and "conv_split" not in k:
         continue
     c, v = fetch[k]
     w = write.get(k, [c, 0.0])[1]

@@ -20,7 +20,13 @@ def load_state_dict(path):
     """A checkpoint file -> {name: float32 ndarray}.  torch is used only here, to read the file (weight loading is the one place the
     north star allows it)."""
     import torch
-    obj = torch.load(path, map_location="cpu", weights_only=False)
+    try:                                    # plain state-dict files (.pth) need no unpickling of arbitrary objects
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:                  # ultralytics .pt checkpoints pickle their model classes: full unpickling executes code from the file
+        import warnings
+        warnings.warn(f"{path}: not loadable with weights_only=True ({type(e).__name__}); falling back to full unpickling — only do this with "
+                      "checkpoints you trust", stacklevel=2)
+        obj = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(obj, dict) and "model" in obj and hasattr(obj["model"], "state_dict"):      # ultralytics checkpoint
         obj = obj["model"].float().state_dict()
     elif hasattr(obj, "state_dict"):

@@ -23,6 +23,7 @@ class CoordinateModel:
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
         self.camera_motion = camera_motion
+        self._tracker_open = False           # the reference builds ONE BotSort in __init__ (cm.py:66-72): ids keep counting across get_coordinates calls
         self.batch = batch
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
                                  det_imgsz=det_imgsz, batch=batch,
@@ -74,9 +75,18 @@ class CoordinateModel:
                 recs = self.handle.reproject(np.ascontiguousarray(recs), Hs, flags)
         return {i: records.to_reference_dict(r, i, fps, own_h=bool(own[i])) for i, r in enumerate(recs)}
 
+    def reset_tracker(self):
+        """Forget every track: the next clip starts with a fresh tracker (frame counter 0, ids from 1), which is what a new
+        ``CoordinateModel`` gives in the reference."""
+        self._tracker_open = False
+
     def _track(self, recs, warps=None):
-        """One clip: track ids + smoothed boxes into the records (frame order), pitch coordinates re-projected on the GPU."""
-        self.handle.track_open()
+        """One clip: track ids + smoothed boxes into the records (frame order), pitch coordinates re-projected on the GPU.  Like the
+        reference's single BotSort instance (cm.py:66-72, 577) the tracker state lives as long as the model: ids keep increasing over
+        successive clips and only the very first frame ever seen activates its tracks at once; ``reset_tracker()`` starts over."""
+        if not self._tracker_open:
+            self.handle.track_open()
+            self._tracker_open = True
         self.handle.track_frames(recs, warps)
         return recs
 

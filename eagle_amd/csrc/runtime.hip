@@ -1399,6 +1399,10 @@ int eagle_debug(const char* key, int64_t value, void* out, int64_t out_bytes)
     EagleHandle* h = nullptr;
     int rc = 0;
     API_BEGIN
+    // The switches are process-wide and change what every handle computes ("skip" drops whole kernels): they only exist for the developer
+    // probes under tools/ and stay inert unless the process opts in.
+    static const bool enabled = getenv("EAGLE_ENABLE_DEBUG") && atoi(getenv("EAGLE_ENABLE_DEBUG")) != 0;
+    if (!enabled) fail(EAGLE_E_STATE, "eagle_debug is disabled: set EAGLE_ENABLE_DEBUG=1 in the environment of a developer probe to use it");
     if (key && !strcmp(key, "skip")) { eagle::g_dbg_skip = (int)value; return EAGLE_OK; }
     rc = eagle::lk_debug(key, value, out, out_bytes);
     if (rc) return EAGLE_E_INVALID;

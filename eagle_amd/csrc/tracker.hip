@@ -135,7 +135,9 @@ void hungarian(const std::vector<double>& a, int n, std::vector<int>& col_of)
 }
 
 // lap.lapjv(cost, extend_cost=True, cost_limit=thresh): leaving a row and a column unmatched costs thresh (thresh / 2 each)
-void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thresh, std::vector<std::pair<int, int>>& m, std::vector<int>& ur, std::vector<int>& uc)
+// fuse: boxmot's fuse_score — cost = 1 - IoU * detection confidence (BoT-SORT applies it to the unconfirmed-track association;
+// boxmot 15.0.2 BotSort._handle_unconfirmed_tracks / the original bot_sort.py "if not self.args.mot20: ious_dists = matching.fuse_score(...)")
+void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thresh, std::vector<std::pair<int, int>>& m, std::vector<int>& ur, std::vector<int>& uc, bool fuse = false)
 {
     m.clear(); ur.clear(); uc.clear();
     const int n = (int)rows.size(), k = (int)cols.size();
@@ -143,7 +145,11 @@ void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thr
     const int N = n + k;
     std::vector<double> ext((size_t)N * N, thresh / 2.0);
     for (int i = n; i < N; ++i) for (int j = k; j < N; ++j) ext[(size_t)i * N + j] = 0.0;
-    for (int i = 0; i < n; ++i) for (int j = 0; j < k; ++j) ext[(size_t)i * N + j] = iou_cost(*rows[i], *cols[j]);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) {
+            const double c = iou_cost(*rows[i], *cols[j]);
+            ext[(size_t)i * N + j] = fuse ? 1.0 - (1.0 - c) * (double)cols[j]->conf : c;
+        }
     std::vector<int> col_of;
     hungarian(ext, N, col_of);
     std::vector<char> cm(k, 0);
@@ -284,7 +290,7 @@ struct Tracker {
         }
         for (int i : ur2) { r_tracked[i]->state = T_LOST; lost_now.push_back(r_tracked[i]); }
         std::vector<int> ur3, uc3;
-        assign(unconfirmed, rest, 0.7, m, ur3, uc3);
+        assign(unconfirmed, rest, 0.7, m, ur3, uc3, true);
         for (auto& ij : m) { update_track(*unconfirmed[ij.first], *rest[ij.second]); activated.push_back(unconfirmed[ij.first]); }
         for (int i : ur3) { unconfirmed[i]->state = T_REMOVED; removed_now.push_back(unconfirmed[i]); }
         for (int j : uc3) {

@@ -31,6 +31,6 @@ class Processor:
         frames = np.ascontiguousarray(frames, np.uint8)
         d = self.model.handle.upload(frames)
         try:
-            return teams.get_team_mapping(self.model.handle, d, coords)
+            return teams.get_team_mapping(self.model.handle, d, coords, n_frames=len(frames))
         finally:
             self.model.handle.free(d)

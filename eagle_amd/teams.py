@@ -31,11 +31,15 @@ def crop_colors(handle, dptr, n_frames, crops):
     return out
 
 
-def get_team_mapping(handle, dptr, coords):
+def get_team_mapping(handle, dptr, coords, n_frames=None):
     """coords: ``{i: {"Coordinates": {"Player": {id: {"BBox": [x1,y1,x2,y2], ...}}}}}`` as ``get_coordinates`` returns it, frame i of the
-    clip at ``dptr`` -> {player_id: 0 | 1}."""
+    clip at ``dptr`` -> {player_id: 0 | 1}.  ``n_frames``: frames resident at ``dptr``; like the reference's ``zip(frames, coords)``
+    (proc.py:408) the walk stops at the shorter of the two, and the kernel never indexes beyond the uploaded clip."""
+    n_frames = len(coords) if n_frames is None else min(int(n_frames), len(coords))
     items, crops = [], []
     for i, key in enumerate(coords):
+        if i >= n_frames:
+            break
         players = coords[key].get("Coordinates", {}).get("Player", {})
         if not players:
             continue
@@ -51,7 +55,7 @@ def get_team_mapping(handle, dptr, coords):
             crops.append((i, *bbox))
     if not crops:
         return {}
-    colors = crop_colors(handle, dptr, len(coords), crops)
+    colors = crop_colors(handle, dptr, n_frames, crops)
     counts = {}
     for (pid, prop), indiv in zip(items, colors):
         d = counts.setdefault(pid, {})

@@ -235,6 +235,7 @@ int eagle_op_find_homography(int device, const float* img_pts, const float* worl
                              int max_iters, int lm_iters, double* H9, uint8_t* mask, int* ok);
 
 /* Developer diagnostics (process-wide switches and read-backs used by tools/probe_lk_concurrency.py; not part of the data path).
+ * Inert (EAGLE_E_STATE) unless the process environment has EAGLE_ENABLE_DEBUG=1: a production caller cannot flip them by accident.
  * Keys: "lk_threads" (64 | 256), "lk_dbg" (1 trace, 2 LDS guard words, 4 end-of-level verification, 8 L1-bypassing loads), "lk_excl_lds" (bytes), "lk_trace", "lk_counters". */
 int eagle_debug(const char* key, int64_t value, void* out, int64_t out_bytes);
 

@@ -15,7 +15,8 @@ the prediction step).  What remains is the motion / IoU part of BoT-SORT exactly
   * detections split by confidence: high (> track_high_thresh 0.5) and low (track_low_thresh 0.1 < c < 0.5);
   * 1st association: tracked + lost tracks vs high detections, cost 1 - IoU, linear assignment with cost limit match_thresh 0.8;
   * 2nd association: the still-unmatched TRACKED tracks vs low detections, cost limit 0.5; unmatched ones become lost;
-  * unconfirmed tracks (born on the previous frame) vs the remaining high detections, cost limit 0.7; unmatched ones are removed;
+  * unconfirmed tracks (born on the previous frame) vs the remaining high detections, cost 1 - IoU * detection confidence (fuse_score),
+    cost limit 0.7; unmatched ones are removed;
   * remaining high detections above new_track_thresh 0.6 start tracks (activated at once only on the first frame);
   * lost tracks are removed after track_buffer 30 frames; duplicate tracked / lost pairs (IoU distance < 0.15) keep the older track;
   * output: the activated tracks in tracked state: (x1, y1, x2, y2 of the filter's posterior, id, conf, cls, detection index).
@@ -229,7 +230,10 @@ class BotSortLite:
             r_tracked[i].state = LOST
             lost_now.append(r_tracked[i])
         rest = [first[j] for j in ud]
-        m3, uu, ud3 = _assign(_iou_cost(unconfirmed, rest), 0.7)
+        c3 = _iou_cost(unconfirmed, rest)
+        if c3.size:                                                        # boxmot's fuse_score: 1 - IoU * detection confidence
+            c3 = 1.0 - (1.0 - c3) * np.array([d.conf for d in rest])[None, :]
+        m3, uu, ud3 = _assign(c3, 0.7)
         for i, j in m3:
             self._update(unconfirmed[i], rest[j], False)
             activated.append(unconfirmed[i])

@@ -114,8 +114,17 @@ def test_coordinate_model_with_tracker_and_camera_motion_runs_both_cadences():
     frames = np.stack([synth.frame(0, t) for t in range(6)])
     cm = CoordinateModel(batch=2, tracker=True, camera_motion=True, detector_conf=0.2)
     a = cm.get_coordinates(frames, fps=1)                                   # key-points on every frame: stateless route
+    ids_a = {k for i in a for k in a[i]["Coordinates"].get("Player", {})}
     b = cm.get_coordinates(frames, fps=24, num_keypoint_detection=3)        # main.py's cadence: clip session
+    ids_b = {k for i in b for k in b[i]["Coordinates"].get("Player", {})}
+    # one tracker for the model's lifetime, like the reference's single BotSort (cm.py:66-72): the second clip continues the first one's
+    # tracks (same frames -> same objects -> ids from the first clip reappear), and reset_tracker() starts from id 1 again
+    cm.reset_tracker()
+    c = cm.get_coordinates(frames, fps=1)
     cm.handle.close()
+    assert c == a
+    if ids_a and ids_b:
+        assert ids_a & ids_b or min(ids_b) > max(ids_a)
     for res in (a, b):
         assert sorted(res) == list(range(6))
         for i in res:

@@ -10,6 +10,8 @@ Two handles, two threads (ctypes releases the GIL).  One process runs a list of 
       corunner also: h_lds h_oob h_mfma h_l1 h_churn h_ldsbyte = synthetic one-feature kernels of tools/lkprobe/hammer.hip
 """
 import os
+os.environ.setdefault("EAGLE_ENABLE_DEBUG", "1")      # eagle_debug is inert without it
+import os
 import sys
 import threading
 import time

@@ -365,7 +365,7 @@ def main():
             res["reference_cadence"] = cadence
         if pcie is not None:
             res["pcie_inclusive"] = pcie
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only (the measurement contract)
             res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())), variant=a.detector, imgsz=a.imgsz)
             # (all 256 hardware threads of the GPU box were tried once: torch-CPU convolutions collapse to 0.004 frames/s, 247 s for one
             #  frame, profiles/r02b_bench_default_1gpu.json, so the bounded sample stays at 16 threads and says so)

@@ -201,3 +201,38 @@ def test_two_ranks_on_one_gpu_equal_a_single_rank_run():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "tools", "shard_check.py")], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0 and "SHARD_CHECK_OK world=2" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def _torchrun(nproc, script_args, extra_env=None, timeout=1500):
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                           "--master-port", str(port)] + script_args, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+def test_eight_ranks_on_one_gpu_ragged_frames_and_nine_clips():
+    """8-GPU pre-flight without the node: eight fresh processes share device 0, 25 frames (chunks of 4: rank 6 holds one frame, rank 7 none),
+    nine clips for eight ranks in the cadence; the gathered records equal a single-rank run (tools/shard_check.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _torchrun(8, [os.path.join(root, "tools", "shard_check.py")], {"SHARD_CHECK_FRAMES": "25", "SHARD_CHECK_BATCH": "2", "OMP_NUM_THREADS": "4"})
+    assert r.returncode == 0 and "SHARD_CHECK_OK world=8 frames=25" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_bench_command_path_at_eight_ranks_on_one_gpu():
+    """The exact command the driver launches for N = 8 (torch.distributed.run ... bench.py --gpus 8 --steps K --warmup W), with the two
+    developer switches that let eight ranks share one device (--shared-gpu, --backend gloo): argument parsing, the barrier-bracketed timed
+    region, the gather inside it, max-over-ranks and the one JSON line have all executed once before a node exists."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _torchrun(8, [os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "4", "--shared-gpu", "--backend", "gloo",
+                      "--no-cpu-baseline"], {"OMP_NUM_THREADS": "4"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["config"]["frames_total"] == 8 * 2 * 4 and res["config"]["gather"] == "dist"

@@ -70,6 +70,17 @@ def test_two_rank_gather_ragged(tmp_path):
     _run(2, 7, tmp_path)            # chunks of 4 and 3: the padded slot must be dropped
 
 
+def test_eight_rank_gather_ragged_with_an_empty_rank(tmp_path):
+    """The driver's N = 8 shape on CPU: 25 frames over 8 ranks = chunks of 4 — ranks 0..5 full, rank 6 one frame, rank 7 NO frame."""
+    from eagle_amd import shard
+    assert [shard.shard_range(25, r, 8) for r in (5, 6, 7)] == [(20, 24), (24, 25), (25, 25)]
+    _run(8, 25, tmp_path)
+
+
+def test_eight_rank_gather_fewer_frames_than_ranks(tmp_path):
+    _run(8, 3, tmp_path)            # chunks of 1: five ranks hold nothing
+
+
 def test_shard_ranges_cover_clip():
     from eagle_amd import shard
     for n in (0, 1, 7, 8, 1000, 8001):
@@ -114,15 +125,24 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_rank_clip_sharding_for_stateful_cadences(tmp_path):
-    """configs[4] shape: whole clips per rank (the optical-flow cadence is sequential within a clip), ragged totals."""
+def _run_clips(world, lengths, tmp_path):
     w = tmp_path / "clip_worker.py"
     w.write_text(CLIP_WORKER)
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, str(w), ROOT, "5,3,9,1,4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(w), ROOT, lengths], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_two_rank_clip_sharding_for_stateful_cadences(tmp_path):
+    """configs[4] shape: whole clips per rank (the optical-flow cadence is sequential within a clip), ragged totals."""
+    _run_clips(2, "5,3,9,1,4", tmp_path)
+
+
+def test_eight_rank_clip_sharding_nine_clips(tmp_path):
+    """configs[4] on the driver's node shape: 9 clips for 8 ranks (chunks of 2 clips: ranks 0..3 two clips, rank 4 one, ranks 5..7 none)."""
+    _run_clips(8, "5,3,9,1,4,7,2,6,8", tmp_path)

@@ -27,17 +27,18 @@ def main():
     from eagle_amd import clip as clipmod
     from eagle_amd import lib, shard, synth, weights
     hs, ys = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("n", 0)
-    B = 4
-    h = lib.Handle(device=0, batch=B, precision=lib.PREC_F16)
+    B = int(os.environ.get("SHARD_CHECK_BATCH", "4"))
+    h = lib.Handle(device=0, batch=B, precision=lib.PRECISIONS[os.environ.get("SHARD_CHECK_PRECISION", "f32s")])
     weights.load_into(h, [hs, ys])
-    # (a) frame-sharded: ragged on purpose (world * B + 3 frames)
-    n = world * B + 3
+    # (a) frame-sharded: ragged on purpose (default world * B + 3 frames; SHARD_CHECK_FRAMES overrides, e.g. 25 frames on 8 ranks = chunks of 4:
+    #     rank 6 holds one frame, rank 7 none)
+    n = int(os.environ.get("SHARD_CHECK_FRAMES", str(world * B + 3)))
     frames = synth.clip(seed=5, n=n)
     lo, hi = shard.shard_range(n, rank, world)
     local = h.process(frames[lo:hi]) if hi > lo else np.zeros(0, lib.RESULT_DTYPE)
     allr = shard.gather_records(local, n, rank, world, transport="dist")
     # (b) clip-sharded cadence: world + 1 clips of different lengths, keypoint_interval 3, homography_interval 6
-    lengths = [7 + 2 * k for k in range(world + 1)]
+    lengths = [7 + 2 * (k % 3) for k in range(world + 1)]
     clips = [synth.clip(seed=20 + k, n=L) for k, L in enumerate(lengths)]
     a, b = shard.shard_range(len(clips), rank, world)
     mine = []

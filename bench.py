@@ -251,10 +251,11 @@ def main():
             hbm_rows.append({"kernel": name, "launches_per_step": launches // prof_steps, "bytes_algorithmic_per_step": round(nbytes / prof_steps),
                              "avg_us": round(ms * 1e3 / launches, 2), "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)})
 
-    def family_run(prec, nframes, Bf, d_frames, hw=(a.height, a.width), det=a.detector, imgsz=a.imgsz, sd=None, want_records=0):
+    def family_run(prec, nframes, Bf, d_frames, hw=(a.height, a.width), det=a.detector, imgsz=a.imgsz, sd=None, want_records=0, det_prec=None):
         """A second handle of another precision family on frames that are already resident: frames/s (K steps of Bf in one call), the
         convolution family's HIP-event roofline, optionally the records of the first `want_records` frames."""
-        hf = lib.Handle(device=dev_index, frame_h=hw[0], frame_w=hw[1], det_variant=det, det_imgsz=imgsz, batch=Bf, precision=lib.PRECISIONS[prec])
+        hf = lib.Handle(device=dev_index, frame_h=hw[0], frame_w=hw[1], det_variant=det, det_imgsz=imgsz, batch=Bf, precision=lib.PRECISIONS[prec],
+                        det_precision=0 if det_prec is None else lib.PRECISIONS[det_prec] + 1)
         weights.load_into(hf, sd or [hs, ys])
         nf = max(Bf, nframes // Bf * Bf)
         of = np.zeros(nf, lib.RESULT_DTYPE)
@@ -304,8 +305,13 @@ def main():
         fast, rec_fast = family_run("f16", a.fast_frames, B, d_clip, want_records=nd)
         fast["note"] = "fp16 tensors, one fp16 MFMA per product: integer outputs are NOT guaranteed equal to the fp32 path's (see parity_counters); reported for reference, never as value"
         log(f"fast family (fp16): {fast['value']} frames/s, conv {fast['roofline']['achieved']:.1f} TFLOP/s")
+        # the mixed handle (EagleConfig::det_precision): key-points in fp16, the detector (1.4 % of the FLOPs) in the split family
+        mixed, rec_mixed = family_run("f16", a.fast_frames, B, d_clip, want_records=nd, det_prec="f32s")
+        fast["with_f32s_detector"] = {"value": mixed["value"], "unit": "frames/s", "note": "fp16 HRNet + f32s YOLOv8: boxes / confidences / NMS order / ids at fp32 grade"}
+        log(f"fast family with the detector in f32s: {mixed['value']} frames/s")
         if parity is not None:
             parity["f16"] = int_field_diffs(rec_fast, rec_exact)
+            parity["f16_with_f32s_detector"] = int_field_diffs(rec_mixed, rec_exact)
     if parity is not None:
         log(f"parity counters vs the exact family: {json.dumps(parity)}")
     if extras and a.cfg3_frames > 0 and (a.height, a.width, a.detector) == (720, 1280, "n"):

@@ -19,7 +19,7 @@ from .pitch import INTERSECTION_TO_PITCH_POINTS
 class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
                  detector="n", det_imgsz=640, batch=8, precision="f16", device=0, hrnet_state_dict=None,
-                 detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False):
+                 detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False, detector_precision=None):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
         self.camera_motion = camera_motion
@@ -28,6 +28,7 @@ class CoordinateModel:
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
                                  det_imgsz=det_imgsz, batch=batch,
                                  precision=lib.PRECISIONS[precision],
+                                 det_precision=0 if detector_precision is None else lib.PRECISIONS[detector_precision] + 1,
                                  keypoint_conf=keypoint_conf, detector_conf=detector_conf,
                                  detector_floor=min(detector_conf, 0.15), use_graph=int(use_graph))
         # the reference reads eagle/models/weights/*.pt|.pth (cm.py:55-59); none exist here -> seeded synthetic

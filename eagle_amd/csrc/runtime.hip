@@ -146,7 +146,7 @@ struct EagleHandle {
     std::string err;
     std::map<std::string, HostTensor> weights;
     bool finalized = false;
-    int prec = 0;
+    int prec = 0, det_prec = 0;              // precision family of the key-point network / of the detector (EagleConfig::det_precision)
     hipStream_t s_main = nullptr, s_det = nullptr, s_post = nullptr, s_copy = nullptr;
     hipStream_t s_br[3] = {nullptr, nullptr, nullptr};          // HRNet branches 1..3 (branch 0 stays on s_main)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -609,7 +609,11 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     const double esz = h->prec == EAGLE_PREC_F16 ? 2 : 4;
     if (!(g_dbg_skip & 16))
         timed(h, "preprocess", (double)n_active * ((double)c.frame_h * c.frame_w * 3 + (540.0 * 960 + (double)h->lb.out_h * h->lb.out_w) * h->kp_in.c * esz), h->s_main,
-              [&] { preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main); });
+              [&] {
+                  if (h->det_prec == h->prec) { preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main); return; }
+                  preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main, 1);        // mixed handle: one pass per tensor format
+                  preprocess_launch(h->det_prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main, 2);
+              });
     const bool two = !h->prof;
     hipStream_t sd = two ? h->s_det : h->s_main;
     if (two) {
@@ -804,7 +808,7 @@ static void clip_detect_objects(EagleHandle* h, int first, int count)
     for (int i = first; i < first + count; i += B) {
         const int na = std::min(B, first + count - i);
         HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_det));
-        preprocess_launch(h->prec, c.cv.bgr + (size_t)i * fb, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_det, 2);
+        preprocess_launch(h->det_prec, c.cv.bgr + (size_t)i * fb, na, cf.frame_h, cf.frame_w, h->kp_in, h->det_in, h->lb, h->s_det, 2);
         run_net(h, h->yo.get(), h->s_det, ev_i);
         yolo_decode_launch(h->levels, 3, B, 5, cf.detector_floor, h->ds, h->s_det);
         nms_launch(h->ds, B, h->pp, sb.d_out, h->s_det);
@@ -848,14 +852,15 @@ static void finalize(EagleHandle* h)
     const EagleConfig& c = h->cfg;
     const int B = c.batch;
     h->prec = c.precision;
+    h->det_prec = c.det_precision ? c.det_precision - 1 : c.precision;
     h->hr.reset(new Net); h->yo.reset(new Net); h->misc.reset(new Net);
-    const int cin_pad = h->prec == EAGLE_PREC_F32 ? 4 : 8;
+    const int cin_pad = h->prec == EAGLE_PREC_F32 ? 4 : 8, det_cin_pad = h->det_prec == EAGLE_PREC_F32 ? 4 : 8;
     h->lb = letterbox_geometry(c.frame_h, c.frame_w, c.det_imgsz);
     // inputs (written by the preprocess kernel)
     Builder Bh{h, h->hr.get(), h->prec, 1e-5, B};
-    Builder By{h, h->yo.get(), h->prec, 1e-3, B};
+    Builder By{h, h->yo.get(), h->det_prec, 1e-3, B};
     h->kp_in = Bh.act(540, 960, cin_pad);
-    h->det_in = By.act(h->lb.out_h, h->lb.out_w, cin_pad);
+    h->det_in = By.act(h->lb.out_h, h->lb.out_w, det_cin_pad);
     h->logits = build_hrnet(Bh, h->kp_in);
     build_yolo(By, h->det_in, c.det_variant, h->levels, 5);
     // scratch
@@ -932,6 +937,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     if (cfg->batch < 1 || cfg->frame_h < 32 || cfg->frame_w < 32) fail(EAGLE_E_INVALID, "bad batch/frame size");
     if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32 && cfg->precision != EAGLE_PREC_F32S) fail(EAGLE_E_INVALID, "bad precision");
     if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
+    if (cfg->det_precision < 0 || cfg->det_precision > EAGLE_PREC_F32S + 1) fail(EAGLE_E_INVALID, "bad detector precision");
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) fail(EAGLE_E_HIP, "device %d not present (%d visible)", cfg->device, ndev);

@@ -25,8 +25,8 @@ class EagleConfig(C.Structure):
                 ("det_imgsz", C.c_int32), ("batch", C.c_int32), ("precision", C.c_int32),
                 ("keypoint_conf", C.c_double), ("detector_conf", C.c_double), ("ransac_thresh", C.c_double),
                 ("detector_floor", C.c_float), ("nms_iou", C.c_float),
-                ("ransac_max_iters", C.c_int32), ("lm_iters", C.c_int32), ("use_graph", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("ransac_max_iters", C.c_int32), ("lm_iters", C.c_int32), ("use_graph", C.c_int32), ("det_precision", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class EagleTimings(C.Structure):

@@ -65,7 +65,9 @@ typedef struct EagleConfig {
     int32_t ransac_max_iters;  /* 2000  cv2 default */
     int32_t lm_iters;          /* 10    cv2 default */
     int32_t use_graph;         /* 1: capture the per-batch step into a hipGraph and replay it */
-    int32_t reserved[7];
+    int32_t det_precision;     /* 0: the detector runs in `precision`; otherwise EAGLE_PREC_* + 1 for the detector alone (e.g. EAGLE_PREC_F32S + 1 in an
+                                  EAGLE_PREC_F16 handle: boxes, confidences, NMS order and ids at fp32 grade for 1.4 % of the FLOPs, key-points in fp16) */
+    int32_t reserved[6];
 } EagleConfig;
 
 typedef struct EagleDet {      /* one row of boxes.xyxy/.conf/.cls after NMS (cm.py:569-572) + cm.py:598-627 */

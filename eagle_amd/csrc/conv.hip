@@ -32,7 +32,7 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
-static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 11; }      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
+static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 12; }      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
 static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
@@ -75,7 +75,9 @@ static const Inst g_ad_inst[] = {
     // A-direct 3x3 kernels (variant 8: BN = 192, tile 4 x 32; 9: BN = 96, tile 8 x 32; 10 / 11: the same for stride 2); kc = 32
     {EAGLE_PREC_F16, 3, 1, 32, 12, 8, nullptr}, {EAGLE_PREC_F16, 3, 1, 32, 6, 9, nullptr}, {EAGLE_PREC_F16, 3, 2, 32, 12, 10, nullptr}, {EAGLE_PREC_F16, 3, 2, 32, 6, 11, nullptr},
     // split family: chunks of 16 logical channels (conv_ad_split.inc)
-    {EAGLE_PREC_F32S, 3, 1, 16, 12, 8, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 9, nullptr}};
+    {EAGLE_PREC_F32S, 3, 1, 16, 12, 8, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 9, nullptr},
+    // split family, Cout = 48 per workgroup: tile 8 x 32, the K dimension split over wave pairs (variant 12)
+    {EAGLE_PREC_F32S, 3, 1, 16, 3, 12, nullptr}};
 
 const Inst* conv_inst_part(int part, int* n)
 {
@@ -131,6 +133,13 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         }
         static const bool sad_on = !(getenv("EAGLE_CONV_AD") && atoi(getenv("EAGLE_CONV_AD")) == 0);
         static const bool tuned_on = !(getenv("EAGLE_CONV_TUNED") && atoi(getenv("EAGLE_CONV_TUNED")) == 0);
+        // (measured on MI355X: 48->48@135x240 305 / 551 us without / with residual against 273 / 322 us of the generic kernel — an 8 x 32 x 48 item is
+        //  21 K-steps per wave, too little work against the exchange, the epilogue and three barriers; kept for the tuner, off by default)
+        const bool kq_on = getenv("EAGLE_CONV_KQ") && atoi(getenv("EAGLE_CONV_KQ")) != 0;      // (read per call: the parity test switches it on)
+        if (sad_on && kq_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 48 == 0 && cout_pad % 96 != 0) {      // Cout = 48 (144, ...): K split over wave pairs
+            ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = 12;
+            return q;
+        }
         if (tuned_on)
             for (const Tuned& t : g_tuned_split)
                 if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
@@ -360,7 +369,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
         const bool split = precision == EAGLE_PREC_F32S;
-        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != (c.variant >= 10 ? 2 : 1) || (split && (c.stride != 1 || c.cin % 48)))
+        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((c.variant == 10 || c.variant == 11) ? 2 : 1) || (split && (c.stride != 1 || c.cin % 48)))
             fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32 (16 in the split family, stride 1 only), 2-byte / split output, pre_act none, post_act in {none, ReLU}");
         if (c.stride == 2) a.nchunks = 4 * c.cin / 32;      // chunks of the space-to-depth image
         const int thh = conv_ad_wide(c) ? 4 : 8;
@@ -370,7 +379,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)

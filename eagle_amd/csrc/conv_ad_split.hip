@@ -12,6 +12,12 @@ namespace eagle {
 #include "conv_kernels.inc"
 #include "conv_ad_split.inc"
 
+ConvKernel conv_ad_split_kernel48(int n_res)           // Cout = 48: one Cout group, two pixel groups, K split over wave pairs (variant 12)
+{
+    static const ConvKernel fn[3] = {conv_split_ad_kernel<1, 2, 0, 2>, conv_split_ad_kernel<1, 2, 1, 2>, conv_split_ad_kernel<1, 2, 2, 2>};
+    return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
+}
+
 ConvKernel conv_ad_split_kernel(bool wide, int n_res)
 {
     static const ConvKernel fn[2][3] = {

@@ -37,5 +37,6 @@ const Inst* conv_inst_split0(int* n); const Inst* conv_inst_split1(int* n); cons
 ConvKernel conv_ad_kernel_s1(bool wide, int n_res);
 ConvKernel conv_ad_kernel_s2(bool wide, int n_res);
 ConvKernel conv_ad_split_kernel(bool wide, int n_res);      // EAGLE_PREC_F32S form (conv_ad_split.inc), stride 1
+ConvKernel conv_ad_split_kernel48(int n_res);               // the same for Cout = 48 (K split over wave pairs; variant 12)
 
 }  // namespace eagle

@@ -3,7 +3,7 @@
 tag=${1:-sq}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc.log 2>&1
 cd $R && python3 - "$O" <<'PY'
 import csv, glob, sys, collections
 O = sys.argv[1]

@@ -19,10 +19,12 @@ from .pitch import INTERSECTION_TO_PITCH_POINTS
 class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
                  detector="n", det_imgsz=640, batch=8, precision="f16", device=0, hrnet_state_dict=None,
-                 detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False, detector_precision=None):
+                 detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False, detector_precision=None,
+                 reid=False, reid_state_dict=None):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
         self.camera_motion = camera_motion
+        self.reid = bool(reid) and tracker      # appearance matching inside the tracker (the reference's BotSort has it on: cm.py:66-72)
         self._tracker_open = False           # the reference builds ONE BotSort in __init__ (cm.py:66-72): ids keep counting across get_coordinates calls
         self.batch = batch
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
@@ -34,7 +36,11 @@ class CoordinateModel:
         # the reference reads eagle/models/weights/*.pt|.pth (cm.py:55-59); none exist here -> seeded synthetic
         hs = hrnet_state_dict if hrnet_state_dict is not None else weights.make_hrnet_state_dict(seed)
         ys = detector_state_dict if detector_state_dict is not None else weights.make_yolo_state_dict(detector, seed)
-        weights.load_into(self.handle, [hs, ys])
+        sds = [hs, ys]
+        if self.reid:                           # the reference downloads osnet_x0_25_msmt17.pt at run time (cm.py:69); none here -> seeded synthetic
+            from . import osnet
+            sds.append(reid_state_dict if reid_state_dict is not None else osnet.make_osnet_state_dict(seed))
+        weights.load_into(self.handle, sds)
 
     # ---- raw records ---------------------------------------------------------------------------------
     def process_records(self, frames):
@@ -49,11 +55,11 @@ class CoordinateModel:
             motion = [] if (self.tracker and self.camera_motion) else None
             recs = self.flow_records(frames, keypoint_interval, homography_interval, calibration, motion=motion)
             if self.tracker:
-                self._track(recs, motion[0] if motion else None)
+                self._track(recs, motion[0] if motion else None, frames)
             return {i: records.to_reference_dict(r, i, fps, own_h=bool(r["pad"][0])) for i, r in enumerate(recs)}
         recs = self.process_records(frames)
         if self.tracker:
-            self._track(recs, self._clip_motion(frames) if self.camera_motion else None)
+            self._track(recs, self._clip_motion(frames) if self.camera_motion else None, frames)
         own = np.ones(len(recs), bool)
         if homography_interval > 1:
             # cm.py:333-367: H is solved on scheduled frames or while the retry flag is set, and carried otherwise.  Every
@@ -81,14 +87,42 @@ class CoordinateModel:
         ``CoordinateModel`` gives in the reference."""
         self._tracker_open = False
 
-    def _track(self, recs, warps=None):
+    def reid_inputs(self, recs, high=0.5):
+        """boxmot extracts appearance features for the high-confidence detections (conf > track_high_thresh) from ``frame[y1:y2, x1:x2]`` of
+        the integer-truncated, frame-clipped box -> (crops [k,5], detection index per crop, crops per record)."""
+        fh, fw = self.handle.cfg.frame_h, self.handle.cfg.frame_w
+        crops, det, count = [], [], []
+        for i, r in enumerate(recs):
+            k = 0
+            for j in range(int(r["n_det"])):
+                d = r["det"][j]
+                if not float(d["conf"]) > high:
+                    continue
+                x1, y1 = max(0, int(d["x1"])), max(0, int(d["y1"]))
+                x2, y2 = min(fw - 1, int(d["x2"])), min(fh - 1, int(d["y2"]))
+                if x2 > x1 and y2 > y1:
+                    crops.append((i, x1, y1, x2, y2)); det.append(j); k += 1
+            count.append(k)
+        return np.asarray(crops, np.int32).reshape(-1, 5), np.asarray(det, np.int32), np.asarray(count, np.int32)
+
+    def _track(self, recs, warps=None, frames=None):
         """One clip: track ids + smoothed boxes into the records (frame order), pitch coordinates re-projected on the GPU.  Like the
         reference's single BotSort instance (cm.py:66-72, 577) the tracker state lives as long as the model: ids keep increasing over
         successive clips and only the very first frame ever seen activates its tracks at once; ``reset_tracker()`` starts over."""
         if not self._tracker_open:
             self.handle.track_open()
             self._tracker_open = True
-        self.handle.track_frames(recs, warps)
+        if self.reid and frames is not None:
+            crops, det, count = self.reid_inputs(recs)
+            frames = np.ascontiguousarray(frames, np.uint8)
+            d = self.handle.upload(frames)
+            try:
+                feats = self.handle.reid_features(d, len(frames), crops)
+            finally:
+                self.handle.free(d)
+            self.handle.track_frames_reid(recs, feats, det, count, warps)
+        else:
+            self.handle.track_frames(recs, warps)
         return recs
 
     def _clip_motion(self, frames):

@@ -151,11 +151,22 @@ void lk_launch(const ClipView& cv, int src_frame, int dst_frame, ChainState* st,
 // ---- team colours (teams.hip, K15) ----------------------------------------------------------------------------------------------
 void team_colors_launch(const uint8_t* d_bgr, int n_frames, int fh, int fw, const EagleCrop* d_crops, int n_crops, int* d_counts, hipStream_t s);
 
+// ---- appearance embeddings for the tracker (reid.hip, K16): OSNet-x0.25 pieces that are not 1 x 1 convolutions -------------------------------
+void reid_crop_launch(const uint8_t* d_bgr, int n_frames, int fh, int fw, const EagleCrop* d_crops, int n, const TView& out, hipStream_t s);
+void reid_conv7_launch(const TView& x, const float* w, const float* b, const TView& y, int n, hipStream_t s);
+void reid_maxpool3s2_launch(const TView& x, const TView& y, int n, hipStream_t s);
+void reid_avgpool2_launch(const TView& x, const TView& y, int n, hipStream_t s);
+void reid_dw3_launch(const TView& x, const float* w, const float* b, const TView& y, int n, hipStream_t s);
+void reid_gate_launch(const TView* streams, const float* w1, const float* b1, const float* w2, const float* b2, int c_real, int r, float* g, const TView& y, int n, hipStream_t s);
+void reid_head_launch(const TView& x, const float* w, const float* b, float* feats, int dim, int n, hipStream_t s);
+
 // ---- track identities (tracker.hip; host side of the library) ----------------------------------------------------------------
 struct Tracker;
 Tracker* tracker_create(const EagleTrackParams* p);
 void tracker_destroy(Tracker* t);
-bool tracker_apply(Tracker* t, EagleFrameResult* rec, int frame_h, int frame_w, double detector_conf, const double* warp = nullptr);   // true: the record's persons are now keyed by track id; warp: 2 x 3 camera motion previous frame -> this one
+// feats / feat_det / n_feat: optional appearance embeddings (EAGLE_REID_DIM floats each) of the detections feat_det[0..n_feat) of this record
+bool tracker_apply(Tracker* t, EagleFrameResult* rec, int frame_h, int frame_w, double detector_conf, const double* warp = nullptr,
+                   const float* feats = nullptr, const int* feat_det = nullptr, int n_feat = 0);   // true: the record's persons are now keyed by track id; warp: 2 x 3 camera motion previous frame -> this one
 void similarity_ransac(const double* p0, const double* p1, int n, double* W6);       // camera motion from matched points (tracker.hip)
 int lk_debug(const char* key, long long value, void* out, long long out_bytes);   // developer diagnostics behind eagle_debug
 // heat-map maxima of `n` frames -> mem[first + k*stride] (threshold / pixel mapping / dedup, cm.py:231-251, 500-518)

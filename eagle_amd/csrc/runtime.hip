@@ -164,7 +164,9 @@ struct EagleHandle {
         hipGraphExec_t gexec = nullptr;
         const uint8_t* g_src = nullptr; int g_n = 0;
     } sb[2];
-    std::unique_ptr<Net> hr, yo, misc;
+    std::unique_ptr<Net> hr, yo, misc, reid;
+    // K16 appearance embeddings (OSNet-x0.25; built when the "reid.*" tensors were loaded): REID_NB crops per pass
+    TView reid_in; float* reid_feats = nullptr; EagleCrop* reid_crops = nullptr; EagleCrop* reid_crops_h = nullptr; float* reid_feats_h = nullptr;
     eagle::Tracker* tracker = nullptr;       // K14 state of the clip being tracked (eagle_track_*)
     std::unique_ptr<CopyPool> pool;          // host-side copy workers (eagle_process_frames from pageable memory)
     // step buffers
@@ -257,10 +259,10 @@ struct Builder {
                 scale[o] = (double)g.data[o] / std::sqrt((double)v.data[o] + bn_eps);
                 bias[o] = (float)((double)b.data[o] - (double)m.data[o] * scale[o]);
             }
-        } else {
+        } else if (H->weights.count(cname + ".bias")) {
             const HostTensor& b = W(cname + ".bias");
             for (int o = 0; o < cout; ++o) bias[o] = b.data[o];
-        }
+        }                                                       // (a linear convolution without BatchNorm and bias: OSNet's LightConv3x3.conv1)
         for (int o = 0; o < cout; ++o)
             for (int i = 0; i < cin; ++i)
                 for (int t = 0; t < ks * ks; ++t) {
@@ -539,6 +541,141 @@ static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3
         a0 += box.h * box.w;
     }
     (void)c1; (void)nc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// OSNet-x0.25 (appearance embeddings of the tracker; architecture table in eagle_amd/osnet.py, kernels in reid.hip).  The 1 x 1
+// convolutions are ordinary Builder convolutions in the exact fp32 family; everything else is a reid_* launch.
+// ------------------------------------------------------------------------------------------------------------
+static const int REID_NB = 64;                  // crops per pass
+static const char* RP = "reid.";
+
+struct ReidFold { std::vector<float> scale, shift; };
+static ReidFold reid_bn(Builder& B, const std::string& bn, int c)
+{
+    const HostTensor &g = B.W(bn + ".weight"), &b = B.W(bn + ".bias"), &m = B.W(bn + ".running_mean"), &v = B.W(bn + ".running_var");
+    ReidFold f; f.scale.resize(c); f.shift.resize(c);
+    for (int o = 0; o < c; ++o) {
+        const double sc = (double)g.data[o] / std::sqrt((double)v.data[o] + 1e-5);
+        f.scale[o] = (float)sc; f.shift[o] = (float)((double)b.data[o] - (double)m.data[o] * sc);
+    }
+    return f;
+}
+
+static TView reid_light(Builder& B, const TView& x, const std::string& lc, int mid)
+{
+    // LightConv3x3: 1x1 linear convolution -> depthwise 3x3 -> BatchNorm -> ReLU
+    TView t = B.conv(x, lc + ".conv1", "", 1, 0, nullptr, nullptr, 0);
+    const HostTensor& w = B.W(lc + ".conv2.weight");                       // [mid, 1, 3, 3]
+    const ReidFold f = reid_bn(B, lc + ".bn", mid);
+    const int C = t.c;
+    std::vector<float> wk((size_t)9 * C, 0.f), bk(C, 0.f);
+    for (int c = 0; c < mid; ++c) {
+        for (int k = 0; k < 9; ++k) wk[(size_t)k * C + c] = (float)((double)w.data[(size_t)c * 9 + k] * (double)f.scale[c]);
+        bk[c] = f.shift[c];
+    }
+    const float* dw = (const float*)B.net->upload(wk.data(), wk.size() * 4);
+    const float* db = (const float*)B.net->upload(bk.data(), bk.size() * 4);
+    TView y = B.act(t.h, t.w, C);
+    const int n = B.N;
+    B.other([t, dw, db, y, n](hipStream_t s) { reid_dw3_launch(t, dw, db, y, n, s); }, "reid dw3x3", 2 * Builder::vbytes(y));
+    B.release(t);
+    return y;
+}
+
+static TView reid_osblock(Builder& B, const TView& x, const std::string& b, int cin, int cout)
+{
+    const int mid = cout / 4, R = ACT_RELU;
+    TView x1 = B.conv(x, b + ".conv1.conv", b + ".conv1.bn", 1, 0, nullptr, nullptr, R);
+    TView st[4];
+    st[0] = reid_light(B, x1, b + ".conv2a", mid);
+    const char* names[3] = {"b", "c", "d"};
+    for (int k = 0; k < 3; ++k) {
+        TView y = x1;
+        for (int d = 0; d < k + 2; ++d) {
+            TView nx = reid_light(B, y, b + ".conv2" + names[k] + "." + std::to_string(d), mid);
+            if (d > 0) B.release(y);
+            y = nx;
+        }
+        st[k + 1] = y;
+    }
+    B.release(x1);
+    // the shared ChannelGate and the four-stream sum
+    const HostTensor &w1 = B.W(b + ".gate.fc1.weight"), &b1 = B.W(b + ".gate.fc1.bias"), &w2 = B.W(b + ".gate.fc2.weight"), &b2 = B.W(b + ".gate.fc2.bias");
+    const int r = (int)w1.shape[0];
+    const float* d1 = (const float*)B.net->upload(w1.data.data(), w1.data.size() * 4);
+    const float* e1 = (const float*)B.net->upload(b1.data.data(), b1.data.size() * 4);
+    const float* d2 = (const float*)B.net->upload(w2.data.data(), w2.data.size() * 4);
+    const float* e2 = (const float*)B.net->upload(b2.data.data(), b2.data.size() * 4);
+    const int C = st[0].c, n = B.N;
+    float* g = (float*)B.net->get((size_t)n * 4 * C * 4);
+    TView x2 = B.act(st[0].h, st[0].w, C);
+    const TView s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3];
+    B.other([s0, s1, s2, s3, d1, e1, d2, e2, mid, r, g, x2, n](hipStream_t s) { const TView ss[4] = {s0, s1, s2, s3}; reid_gate_launch(ss, d1, e1, d2, e2, mid, r, g, x2, n, s); },
+            "reid gate", 5 * Builder::vbytes(x2));
+    for (auto& t : st) B.release(t);
+    TView ident = x;
+    if (cin != cout) ident = B.conv(x, b + ".downsample.conv", b + ".downsample.bn", 1, 0, nullptr, nullptr, 0);
+    TView y = B.conv(x2, b + ".conv3.conv", b + ".conv3.bn", 1, 0, &ident, nullptr, R);       // relu(conv3(x2) + identity): the residual add is commutative
+    B.release(x2);
+    if (cin != cout) B.release(ident);
+    return y;
+}
+
+static void build_reid(Builder& B, EagleHandle* h)
+{
+    const std::string P = RP;
+    const int n = B.N;
+    h->reid_in = B.act(256, 128, 4);
+    // stem: 7 x 7 / 2 convolution + BatchNorm + ReLU (weights [7][7][3][16] with the BN scale folded in), 3 x 3 / 2 max-pool
+    const HostTensor& w1 = B.W(P + "conv1.conv.weight");                    // [16, 3, 7, 7]
+    const ReidFold f1 = reid_bn(B, P + "conv1.bn", 16);
+    std::vector<float> wk(7 * 7 * 3 * 16), bk(16);
+    for (int o = 0; o < 16; ++o) {
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 49; ++k) wk[(size_t)(k * 3 + c) * 16 + o] = (float)((double)w1.data[((size_t)o * 3 + c) * 49 + k] * (double)f1.scale[o]);
+        bk[o] = f1.shift[o];
+    }
+    const float* dw = (const float*)B.net->upload(wk.data(), wk.size() * 4);
+    const float* db = (const float*)B.net->upload(bk.data(), bk.size() * 4);
+    TView c1 = B.act(128, 64, 16);
+    const TView in = h->reid_in;
+    B.other([in, dw, db, c1, n](hipStream_t s) { reid_conv7_launch(in, dw, db, c1, n, s); }, "reid conv7x7", Builder::vbytes(in) + Builder::vbytes(c1));
+    TView x = B.act(64, 32, 16);
+    B.other([c1, x, n](hipStream_t s) { reid_maxpool3s2_launch(c1, x, n, s); }, "reid maxpool", Builder::vbytes(c1) + Builder::vbytes(x));
+    B.release(c1);
+    static const int CH[4] = {16, 64, 96, 128};
+    const char* stage[3] = {"conv2", "conv3", "conv4"};
+    for (int sI = 0; sI < 3; ++sI) {
+        const int cin = CH[sI], cout = CH[sI + 1];
+        const std::string sp = P + stage[sI];
+        TView y = reid_osblock(B, x, sp + ".0", cin, cout); B.release(x); x = y;
+        y = reid_osblock(B, x, sp + ".1", cout, cout); B.release(x); x = y;
+        if (sI < 2) {                                       // transition: Conv1x1 + BN + ReLU, AvgPool2d(2, 2)
+            TView t = B.conv(x, sp + ".2.0.conv", sp + ".2.0.bn", 1, 0, nullptr, nullptr, ACT_RELU); B.release(x);
+            TView p = B.act(t.h / 2, t.w / 2, t.c);
+            B.other([t, p, n](hipStream_t s) { reid_avgpool2_launch(t, p, n, s); }, "reid avgpool", Builder::vbytes(t) + Builder::vbytes(p));
+            B.release(t);
+            x = p;
+        }
+    }
+    TView c5 = B.conv(x, P + "conv5.conv", P + "conv5.bn", 1, 0, nullptr, nullptr, ACT_RELU); B.release(x);
+    // head: global average -> Linear(128, 512) + bias -> BatchNorm1d -> ReLU, the BN folded into the linear layer
+    const HostTensor &fw = B.W(P + "fc.0.weight"), &fb = B.W(P + "fc.0.bias");
+    const ReidFold ff = reid_bn(B, P + "fc.1", EAGLE_REID_DIM);
+    std::vector<float> hw((size_t)EAGLE_REID_DIM * c5.c, 0.f), hb(EAGLE_REID_DIM);
+    for (int o = 0; o < EAGLE_REID_DIM; ++o) {
+        for (int c = 0; c < 128; ++c) hw[(size_t)o * c5.c + c] = (float)((double)fw.data[(size_t)o * 128 + c] * (double)ff.scale[o]);
+        hb[o] = (float)((double)fb.data[o] * (double)ff.scale[o] + (double)ff.shift[o]);
+    }
+    const float* dhw = (const float*)B.net->upload(hw.data(), hw.size() * 4);
+    const float* dhb = (const float*)B.net->upload(hb.data(), hb.size() * 4);
+    h->reid_feats = (float*)B.net->get((size_t)n * EAGLE_REID_DIM * 4);
+    float* feats = h->reid_feats;
+    B.other([c5, dhw, dhb, feats, n](hipStream_t s) { reid_head_launch(c5, dhw, dhb, feats, EAGLE_REID_DIM, n, s); }, "reid head", Builder::vbytes(c5));
+    h->reid_crops = (EagleCrop*)B.net->get(sizeof(EagleCrop) * (size_t)n);
+    HIP_CHECK(hipHostMalloc((void**)&h->reid_crops_h, sizeof(EagleCrop) * (size_t)n, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&h->reid_feats_h, sizeof(float) * EAGLE_REID_DIM * (size_t)n, hipHostMallocDefault));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -863,6 +1000,11 @@ static void finalize(EagleHandle* h)
     h->det_in = By.act(h->lb.out_h, h->lb.out_w, det_cin_pad);
     h->logits = build_hrnet(Bh, h->kp_in);
     build_yolo(By, h->det_in, c.det_variant, h->levels, 5);
+    if (h->weights.count(std::string(RP) + "conv1.conv.weight")) {          // appearance embeddings for the tracker: only when the caller loaded an OSNet
+        h->reid.reset(new Net);
+        Builder Br{h, h->reid.get(), EAGLE_PREC_F32, 1e-5, REID_NB};
+        build_reid(Br, h);
+    }
     // scratch
     Net* m = h->misc.get();
     for (auto& sb : h->sb) {
@@ -977,7 +1119,9 @@ void eagle_destroy(EagleHandle* h)
     }
     for (auto& e : h->conv_ev) (void)hipEventDestroy(e);
     for (auto& e : h->span_pool) (void)hipEventDestroy(e);
-    h->hr.reset(); h->yo.reset(); h->misc.reset();
+    h->hr.reset(); h->yo.reset(); h->misc.reset(); h->reid.reset();
+    if (h->reid_crops_h) (void)hipHostFree(h->reid_crops_h);
+    if (h->reid_feats_h) (void)hipHostFree(h->reid_feats_h);
     if (h->s_main) (void)hipStreamDestroy(h->s_main);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
     if (h->s_post) (void)hipStreamDestroy(h->s_post);
@@ -1135,6 +1279,33 @@ int eagle_team_colors(EagleHandle* h, const void* d_bgr, int n_frames, const Eag
     API_END(h)
 }
 
+int eagle_reid_features(EagleHandle* h, const void* d_bgr, int n_frames, const EagleCrop* crops, int n_crops, float* feats)
+{
+    if (!h) return EAGLE_E_INVALID;
+    API_BEGIN
+    if (!h->finalized || !h->reid) fail(EAGLE_E_STATE, "no appearance network: load the reid.* tensors (OSNet-x0.25, torchreid names) before eagle_finalize_weights");
+    if (!d_bgr || n_frames < 0 || n_crops < 0 || (n_crops > 0 && (!crops || !feats))) fail(EAGLE_E_INVALID, "bad argument");
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    const bool prof = h->prof; h->prof = false;
+    for (int i0 = 0; i0 < n_crops; i0 += eagle::REID_NB) {
+        const int nb = std::min(eagle::REID_NB, n_crops - i0);
+        for (int k = 0; k < eagle::REID_NB; ++k) {
+            EagleCrop c = {-1, 0, 0, 0, 0};
+            if (k < nb) c = crops[i0 + k];
+            h->reid_crops_h[k] = c;
+        }
+        HIP_CHECK(hipMemcpyAsync(h->reid_crops, h->reid_crops_h, sizeof(EagleCrop) * eagle::REID_NB, hipMemcpyHostToDevice, h->s_main));
+        eagle::reid_crop_launch((const uint8_t*)d_bgr, n_frames, h->cfg.frame_h, h->cfg.frame_w, h->reid_crops, eagle::REID_NB, h->reid_in, h->s_main);
+        size_t ev_i = 0;
+        eagle::run_net(h, h->reid.get(), h->s_main, ev_i);
+        HIP_CHECK(hipMemcpyAsync(h->reid_feats_h, h->reid_feats, sizeof(float) * EAGLE_REID_DIM * (size_t)nb, hipMemcpyDeviceToHost, h->s_main));
+        HIP_CHECK(hipStreamSynchronize(h->s_main));
+        memcpy(feats + (size_t)i0 * EAGLE_REID_DIM, h->reid_feats_h, sizeof(float) * EAGLE_REID_DIM * (size_t)nb);
+    }
+    h->prof = prof;
+    API_END(h)
+}
+
 int eagle_track_open(EagleHandle* h, const EagleTrackParams* params)
 {
     if (!h) return EAGLE_E_INVALID;
@@ -1146,18 +1317,25 @@ int eagle_track_open(EagleHandle* h, const EagleTrackParams* params)
 
 int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n) { return eagle_track_frames_cmc(h, recs, n, nullptr); }
 
-int eagle_track_frames_cmc(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps)
+int eagle_track_frames_cmc(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps) { return eagle_track_frames_reid(h, recs, n, warps, nullptr, nullptr, nullptr); }
+
+int eagle_track_frames_reid(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps, const float* feats, const int32_t* feat_det, const int32_t* feat_count)
 {
     if (!h) return EAGLE_E_INVALID;
     API_BEGIN
-    if (!recs || n < 0) fail(EAGLE_E_INVALID, "bad argument");
+    if (!recs || n < 0 || (feats && (!feat_det || !feat_count))) fail(EAGLE_E_INVALID, "bad argument");
     if (!h->tracker) fail(EAGLE_E_STATE, "eagle_track_open has not been called");
     if (n == 0) return EAGLE_OK;
     std::vector<double> Hs((size_t)n * 9, 0.0);
     std::vector<uint8_t> flags((size_t)n, 0);
     bool any = false;
+    size_t fo = 0;                                           // running offset into feats / feat_det
     for (int i = 0; i < n; ++i) {
-        if (!eagle::tracker_apply(h->tracker, recs + i, h->cfg.frame_h, h->cfg.frame_w, h->cfg.detector_conf, warps ? warps + (size_t)i * 6 : nullptr)) continue;
+        const int nf = feats ? feat_count[i] : 0;
+        const bool applied = eagle::tracker_apply(h->tracker, recs + i, h->cfg.frame_h, h->cfg.frame_w, h->cfg.detector_conf, warps ? warps + (size_t)i * 6 : nullptr,
+                                                  feats ? feats + fo * EAGLE_REID_DIM : nullptr, feats ? feat_det + fo : nullptr, nf);
+        fo += (size_t)nf;
+        if (!applied) continue;
         any = true;
         flags[i] = recs[i].H_valid ? 1 : 2;                  // re-project the moved foot points with the frame's own homography
         memcpy(&Hs[(size_t)i * 9], recs[i].H, sizeof(double) * 9);

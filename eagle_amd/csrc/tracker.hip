@@ -30,6 +30,19 @@ struct Track {
     float conf = 0; int cls = 0, det_ind = -1;
     int state = T_NEW, id = -1, frame_id = 0, start_frame = 0;
     bool is_activated = false;
+    // appearance (BoT-SORT with_reid): the detection's normalised embedding and the track's exponential moving average of them (alpha 0.9, re-normalised)
+    std::vector<double> curr_feat, smooth_feat;
+    void update_features(const std::vector<double>& f)
+    {
+        if (f.empty()) return;
+        curr_feat = f;
+        if (smooth_feat.empty()) smooth_feat = f;
+        else for (size_t k = 0; k < f.size(); ++k) smooth_feat[k] = 0.9 * smooth_feat[k] + 0.1 * f[k];
+        double n2 = 0;
+        for (double v : smooth_feat) n2 += v * v;
+        const double nn = std::sqrt(n2);
+        if (nn > 0) for (double& v : smooth_feat) v /= nn;
+    }
     void xyxy(double* b) const
     {
         const double* c = has_state ? mean : z;
@@ -137,7 +150,18 @@ void hungarian(const std::vector<double>& a, int n, std::vector<int>& col_of)
 // lap.lapjv(cost, extend_cost=True, cost_limit=thresh): leaving a row and a column unmatched costs thresh (thresh / 2 each)
 // fuse: boxmot's fuse_score — cost = 1 - IoU * detection confidence (BoT-SORT applies it to the unconfirmed-track association;
 // boxmot 15.0.2 BotSort._handle_unconfirmed_tracks / the original bot_sort.py "if not self.args.mot20: ious_dists = matching.fuse_score(...)")
-void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thresh, std::vector<std::pair<int, int>>& m, std::vector<int>& ur, std::vector<int>& uc, bool fuse = false)
+// scipy cdist(..., "cosine") as boxmot's embedding_distance uses it: 1 - u.v / (|u| |v|), clipped at 0
+double cosine_distance(const std::vector<double>& u, const std::vector<double>& v)
+{
+    double uv = 0, uu = 0, vv = 0;
+    for (size_t k = 0; k < u.size(); ++k) { uv += u[k] * v[k]; uu += u[k] * u[k]; vv += v[k] * v[k]; }
+    const double d = 1.0 - uv / (std::sqrt(uu) * std::sqrt(vv));
+    return d > 0.0 ? d : 0.0;
+}
+
+// reid: BoT-SORT's appearance fusion — emb = cosine distance(track smooth feature, detection feature) / 2; emb > appearance_thresh 0.25 -> 1;
+// IoU distance (before the score fusion) > proximity_thresh 0.5 -> emb = 1; cost = min(IoU cost, emb).  Pairs without both features keep the IoU cost.
+void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thresh, std::vector<std::pair<int, int>>& m, std::vector<int>& ur, std::vector<int>& uc, bool fuse = false, bool reid = false)
 {
     m.clear(); ur.clear(); uc.clear();
     const int n = (int)rows.size(), k = (int)cols.size();
@@ -148,7 +172,14 @@ void assign(const std::vector<TP>& rows, const std::vector<TP>& cols, double thr
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < k; ++j) {
             const double c = iou_cost(*rows[i], *cols[j]);
-            ext[(size_t)i * N + j] = fuse ? 1.0 - (1.0 - c) * (double)cols[j]->conf : c;
+            double cost = fuse ? 1.0 - (1.0 - c) * (double)cols[j]->conf : c;
+            if (reid && !rows[i]->smooth_feat.empty() && !cols[j]->curr_feat.empty()) {
+                double e = cosine_distance(rows[i]->smooth_feat, cols[j]->curr_feat) / 2.0;
+                if (e > 0.25) e = 1.0;
+                if (c > 0.5) e = 1.0;
+                cost = std::min(cost, e);
+            }
+            ext[(size_t)i * N + j] = cost;
         }
     std::vector<int> col_of;
     hungarian(ext, N, col_of);
@@ -241,14 +272,16 @@ struct Tracker {
     void update_track(Track& t, const Track& d)
     {
         kf_update(t, d.z);
+        t.update_features(d.curr_feat);
         t.state = T_TRACKED; t.is_activated = true; t.frame_id = frame_id;
         t.conf = d.conf; t.cls = d.cls; t.det_ind = d.det_ind;
     }
     // dets: x1,y1,x2,y2,conf,cls rows -> the activated tracked tracks
     // warp: optional 2 x 3 camera motion of the previous frame -> this one, applied after the prediction like BoT-SORT's multi_gmc
-    void update(const EagleDet* dets, int n, std::vector<TP>& out, const double* warp = nullptr)
+    void update(const EagleDet* dets, int n, std::vector<TP>& out, const double* warp = nullptr, const float* feats = nullptr, const int* feat_det = nullptr, int n_feat = 0)
     {
         ++frame_id;
+        const bool reid = feats != nullptr;
         std::vector<TP> first, second;
         for (int i = 0; i < n; ++i) {
             const EagleDet& d = dets[i];
@@ -258,6 +291,17 @@ struct Tracker {
             const double x1 = d.x1, y1 = d.y1, x2 = d.x2, y2 = d.y2;
             t->z[0] = (x1 + x2) / 2; t->z[1] = (y1 + y2) / 2; t->z[2] = x2 - x1; t->z[3] = y2 - y1;
             t->conf = d.conf; t->cls = d.cls; t->det_ind = i;
+            if (reid && c > hi)                               // boxmot extracts features for the high-confidence set only
+                for (int k = 0; k < n_feat; ++k)
+                    if (feat_det[k] == i) {
+                        std::vector<double> f(EAGLE_REID_DIM);
+                        double n2 = 0;
+                        for (int q = 0; q < EAGLE_REID_DIM; ++q) { f[q] = feats[(size_t)k * EAGLE_REID_DIM + q]; n2 += f[q] * f[q]; }
+                        const double nn = std::sqrt(n2);
+                        if (nn > 0) for (double& v : f) v /= nn;      // STrack.update_features: feat /= np.linalg.norm(feat)
+                        t->curr_feat = f;
+                        break;
+                    }
             (c > hi ? first : second).push_back(t);
         }
         std::vector<TP> unconfirmed, act, pool;
@@ -271,7 +315,7 @@ struct Tracker {
         if (warp) { for (auto& t : pool) apply_warp(*t, warp); for (auto& t : unconfirmed) apply_warp(*t, warp); }
         std::vector<TP> activated, refind, lost_now, removed_now;
         std::vector<std::pair<int, int>> m; std::vector<int> ur, uc;
-        assign(pool, first, match, m, ur, uc);
+        assign(pool, first, match, m, ur, uc, false, reid);
         for (auto& ij : m) {
             TP& t = pool[ij.first];
             (t->state == T_TRACKED ? activated : refind).push_back(t);
@@ -290,13 +334,14 @@ struct Tracker {
         }
         for (int i : ur2) { r_tracked[i]->state = T_LOST; lost_now.push_back(r_tracked[i]); }
         std::vector<int> ur3, uc3;
-        assign(unconfirmed, rest, 0.7, m, ur3, uc3, true);
+        assign(unconfirmed, rest, 0.7, m, ur3, uc3, true, reid);
         for (auto& ij : m) { update_track(*unconfirmed[ij.first], *rest[ij.second]); activated.push_back(unconfirmed[ij.first]); }
         for (int i : ur3) { unconfirmed[i]->state = T_REMOVED; removed_now.push_back(unconfirmed[i]); }
         for (int j : uc3) {
             TP& t = rest[j];
             if (!((double)t->conf >= newt)) continue;
             kf_initiate(*t);
+            t->update_features(t->curr_feat);
             t->id = next_id++;
             t->state = T_TRACKED; t->is_activated = frame_id == 1;
             t->frame_id = t->start_frame = frame_id;
@@ -343,11 +388,11 @@ void tracker_destroy(Tracker* t) { delete t; }
 
 // cm.py:577-616 on one record: track rows -> Player / Goalkeeper entries keyed by track id (smoothed boxes); when the tracker reports
 // no player at all the reference falls back to the raw detections keyed by detection index — which is what the record already holds.
-bool tracker_apply(Tracker* T, EagleFrameResult* R, int frame_h, int frame_w, double detector_conf, const double* warp)
+bool tracker_apply(Tracker* T, EagleFrameResult* R, int frame_h, int frame_w, double detector_conf, const double* warp, const float* feats, const int* feat_det, int n_feat)
 {
     std::vector<TP> out;
     const int n = std::max(0, std::min(R->n_det, EAGLE_MAX_DET));
-    T->update(R->det, n, out, warp);
+    T->update(R->det, n, out, warp, feats, feat_det, n_feat);
     int persons = 0;
     for (auto& t : out) persons += (t->cls == 0 || t->cls == 1) && !((double)t->conf < detector_conf);
     if (persons == 0) return false;

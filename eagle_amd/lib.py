@@ -112,6 +112,8 @@ def load():
     L.eagle_track_frames.argtypes = [vp, vp, i32]
     L.eagle_track_frames_cmc.argtypes = [vp, vp, i32, C.POINTER(C.c_double)]
     L.eagle_clip_motion.argtypes = [vp, i32, i32, C.POINTER(C.c_double)]
+    L.eagle_reid_features.argtypes = [vp, vp, i32, vp, i32, fp]
+    L.eagle_track_frames_reid.argtypes = [vp, vp, i32, C.POINTER(C.c_double), fp, C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
 
@@ -121,7 +123,8 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
-           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_track_frames_cmc", "eagle_clip_motion", "eagle_team_colors"]
+           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_track_frames_cmc", "eagle_clip_motion", "eagle_team_colors",
+           "eagle_reid_features", "eagle_track_frames_reid"]
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
 E_REFERENCE_RAISES = -7
@@ -308,6 +311,25 @@ class Handle:
             d.update(params)
             p = C.byref(EagleTrackParams(**d))
         self._check(self.L.eagle_track_open(self._h, p), "track_open")
+
+    def reid_features(self, dptr, n_frames, crops):
+        """crops: int32 [k,5] (frame, x1, y1, x2, y2) of a clip resident in HBM -> float32 [k, 512] OSNet-x0.25 embeddings (needs the reid.* weights)."""
+        crops = np.ascontiguousarray(crops, np.int32).reshape(-1, 5)
+        out = np.zeros((len(crops), 512), np.float32)
+        self._check(self.L.eagle_reid_features(self._h, dptr, n_frames, crops.ctypes.data_as(C.c_void_p), len(crops), out.ctypes.data_as(C.POINTER(C.c_float))), "reid_features")
+        return out
+
+    def track_frames_reid(self, recs, feats, feat_det, feat_count, warps=None):
+        """track_frames with appearance: record i owns feat_count[i] consecutive rows of feats; feat_det = their detection indices."""
+        assert recs.dtype == RESULT_DTYPE and recs.flags.c_contiguous
+        feats = np.ascontiguousarray(feats, np.float32).reshape(-1, 512)
+        feat_det = np.ascontiguousarray(feat_det, np.int32); feat_count = np.ascontiguousarray(feat_count, np.int32)
+        assert len(feat_count) == len(recs) and int(feat_count.sum()) == len(feats) == len(feat_det)
+        w = None if warps is None else np.ascontiguousarray(warps, np.float64).reshape(len(recs), 6)
+        self._check(self.L.eagle_track_frames_reid(self._h, recs.ctypes.data_as(C.c_void_p), len(recs), None if w is None else w.ctypes.data_as(C.POINTER(C.c_double)),
+                                                   feats.ctypes.data_as(C.POINTER(C.c_float)), feat_det.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   feat_count.ctypes.data_as(C.POINTER(C.c_int32))), "track_frames_reid")
+        return recs
 
     def track_frames(self, recs, warps=None):
         """In place: the next records of the clip being tracked (frame order).  warps: optional [len(recs), 6] camera motions (clip_motion)."""

@@ -182,6 +182,7 @@ int eagle_clip_close(EagleHandle* h);
  * clip in frame order (call it chunk after chunk; eagle_track_open starts a new clip): Player / Goalkeeper entries become keyed by
  * track id with the filter's boxes and feet (cm.py:577-596; frames on which the tracker reports no player keep the detection-index
  * fallback of cm.py:598-616), then the pitch coordinates of the moved foot points are recomputed on the GPU with each record's H. */
+typedef struct EagleCrop { int32_t frame, x1, y1, x2, y2; } EagleCrop;      /* frame[y1:y2, x1:x2] of a clip resident in HBM */
 typedef struct EagleTrackParams {
     float track_high_thresh, track_low_thresh, new_track_thresh, match_thresh;   /* 0.5, 0.1, 0.6, 0.8 (boxmot defaults) */
     int32_t track_buffer, frame_rate;                                             /* 30, 30 */
@@ -194,11 +195,21 @@ int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n);
  * (identity for clip frame 0).  eagle_track_frames_cmc: as eagle_track_frames, applying warps[6 * i] to all track states before frame i is associated. */
 int eagle_clip_motion(EagleHandle* h, int first, int count, double* warps);
 int eagle_track_frames_cmc(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps /* NULL: none */);
+/* Appearance (BoT-SORT with_reid, the reference's configuration: cm.py:66-72 builds BotSort with osnet_x0_25 ReID weights and passes the frame at
+ * cm.py:577).  eagle_reid_features: OSNet-x0.25 embeddings (EAGLE_REID_DIM floats each) of crops frame[y1:y2, x1:x2] of a clip resident in HBM,
+ * prepared as boxmot does (resize to 128 x 256, RGB, ImageNet normalisation); needs the "reid.*" tensors (torchreid's parameter names) loaded
+ * before eagle_finalize_weights, EAGLE_E_STATE otherwise.  eagle_track_frames_reid: as eagle_track_frames_cmc with the embeddings of each
+ * record's high-confidence detections: record i owns feat_count[i] consecutive rows of `feats`, feat_det lists their detection indices.  The
+ * association then is BoT-SORT's: cost = min(IoU distance, embedding distance / 2) with embedding distances above appearance_thresh 0.25 or IoU
+ * distances above proximity_thresh 0.5 set to 1; track features are exponential moving averages (alpha 0.9) of the normalised embeddings. */
+#define EAGLE_REID_DIM 512
+int eagle_reid_features(EagleHandle* h, const void* d_bgr, int n_frames, const EagleCrop* crops, int n_crops, float* feats);
+int eagle_track_frames_reid(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps /* NULL: none */, const float* feats,
+                            const int32_t* feat_det, const int32_t* feat_count);
 
 /* ---- team colours: Processor.detect_color, eagle/processor.py:466-503, for player crops of a clip resident in HBM -----
  * counts[12 * i + k]: pixels of crop i's player cluster inside colour range k of proc.py:10-23, k = red (red2 merged), orange, yellow,
  * green, cyan, blue, purple, magenta, white, gray, black; slot 11 = pixels of the player cluster.  Crops are frame[y1:y2, x1:x2]. */
-typedef struct EagleCrop { int32_t frame, x1, y1, x2, y2; } EagleCrop;
 int eagle_team_colors(EagleHandle* h, const void* d_bgr, int n_frames, const EagleCrop* crops, int n_crops, int32_t* counts);
 
 /* Frame-sharded multi-GPU: rank r owns a contiguous chunk; one RCCL all-gather of records.

@@ -4,8 +4,8 @@ BoT-SORT track association as the reference runs it behind ``self.tracker.update
 (eagle/models/coordinate_model.py:66-72, 574-596; boxmot 15.0.2 ``BotSort``, uv.lock:98-99 — NOT in /root/reference and absent from
 this image: restated from the published algorithm (Aharon et al. 2022; ByteTrack's two-stage association), PARITY UNPINNED).
 
-Stated deviations from the reference's configuration: appearance (OSNet ReID, ``with_reid=True``) is OFF (the checkpoint does
-not exist here).  Camera-motion compensation: boxmot's default is ECC on the gray frame (cv2, absent); here the warp is a similarity transform
+Appearance (``with_reid=True``, the reference's configuration): ``update(..., feats=)`` takes the OSNet embeddings of the high-confidence
+detections (oracle/reid.py) and fuses them as BoT-SORT does.  Stated deviation: camera-motion compensation: boxmot's default is ECC on the gray frame (cv2, absent); here the warp is a similarity transform
 estimated from a fixed 8 x 6 grid of points tracked by the pyramidal LK of the key-point cadence (``camera_motion``: the same K12 kernel on the
 GPU side), RANSAC over point pairs + least squares on the consensus set — BoT-SORT's own "sparseOptFlow" alternative with a fixed grid instead
 of a corner detector.  The warp is applied as BoT-SORT's ``multi_gmc`` does (means and covariances of all pooled and unconfirmed tracks, after
@@ -146,6 +146,17 @@ class _Track:
         self.mean = self.cov = None
         self.state, self.is_activated, self.id = NEW, False, -1
         self.frame_id = self.start_frame = 0
+        self.curr_feat = self.smooth_feat = None
+
+    def update_features(self, feat):
+        """STrack.update_features: exponential moving average (alpha 0.9) of the normalised embeddings, re-normalised"""
+        if feat is None:
+            return
+        self.curr_feat = feat
+        self.smooth_feat = feat.copy() if self.smooth_feat is None else 0.9 * self.smooth_feat + 0.1 * feat
+        n = np.linalg.norm(self.smooth_feat)
+        if n > 0:
+            self.smooth_feat = self.smooth_feat / n
 
     def xyxy(self):
         c = self.z if self.mean is None else self.mean[:4]
@@ -163,6 +174,22 @@ def _iou_cost(tracks, dets):
                 inter = iw * ih
                 c[i, j] = 1.0 - inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
     return c
+
+
+def _fuse_appearance(cost, iou_raw, tracks, dets):
+    """BoT-SORT with_reid: emb = cosine distance / 2; emb > appearance_thresh 0.25 -> 1; IoU distance > proximity_thresh 0.5 -> emb = 1;
+    cost = min(cost, emb) for every pair with both features."""
+    out = cost.copy()
+    for i, t in enumerate(tracks):
+        for j, d in enumerate(dets):
+            if t.smooth_feat is None or d.curr_feat is None:
+                continue
+            u, v = t.smooth_feat, d.curr_feat
+            e = max(0.0, 1.0 - float(u @ v) / (np.sqrt(float(u @ u)) * np.sqrt(float(v @ v)))) / 2.0
+            if e > 0.25 or iou_raw[i, j] > 0.5:
+                e = 1.0
+            out[i, j] = min(out[i, j], e)
+    return out
 
 
 def _assign(cost, thresh):
@@ -189,21 +216,31 @@ class BotSortLite:
 
     def _activate(self, t):
         t.mean, t.cov = _KF.initiate(t.z)
+        t.update_features(t.curr_feat)
         t.id = self.next_id; self.next_id += 1
         t.state, t.is_activated = TRACKED, self.frame_id == 1
         t.frame_id = t.start_frame = self.frame_id
 
     def _update(self, t, d, reactivate):
         t.mean, t.cov = _KF.update(t.mean, t.cov, d.z)
+        t.update_features(d.curr_feat)
         t.state, t.is_activated, t.frame_id = TRACKED, True, self.frame_id
         t.conf, t.cls, t.det_ind = d.conf, d.cls, d.det_ind
 
-    def update(self, dets, warp=None):
+    def update(self, dets, warp=None, feats=None):
         """dets: [n,6] x1,y1,x2,y2,conf,cls -> [m,8] x1,y1,x2,y2,id,conf,cls,det_ind (as boxmot returns it).  warp: optional 2 x 3 camera
-        motion of the previous frame -> this one (applied after the prediction, like BoT-SORT's gmc)."""
+        motion of the previous frame -> this one (applied after the prediction, like BoT-SORT's gmc).  feats: optional {detection index:
+        512-d embedding} of the high-confidence detections (with_reid, the reference's configuration)."""
         self.frame_id += 1
         dets = np.asarray(dets, np.float64).reshape(-1, 6)
         first = [_Track(d, i) for i, d in enumerate(dets) if d[4] > self.hi]
+        if feats is not None:
+            for t in first:
+                f = feats.get(t.det_ind)
+                if f is not None:
+                    f = np.asarray(f, np.float64)
+                    n = np.linalg.norm(f)
+                    t.curr_feat = f / n if n > 0 else f
         second = [_Track(d, i) for i, d in enumerate(dets) if self.lo < d[4] < self.hi]
         unconfirmed = [t for t in self.tracked if not t.is_activated]
         tracked = [t for t in self.tracked if t.is_activated]
@@ -215,7 +252,10 @@ class BotSortLite:
         apply_warp(pool, warp)
         apply_warp(unconfirmed, warp)
         activated, refind, lost_now, removed = [], [], [], []
-        m, ut, ud = _assign(_iou_cost(pool, first), self.match)
+        c1 = _iou_cost(pool, first)
+        if feats is not None:
+            c1 = _fuse_appearance(c1, c1, pool, first)
+        m, ut, ud = _assign(c1, self.match)
         for i, j in m:
             t = pool[i]
             (activated if t.state == TRACKED else refind).append(t)
@@ -231,8 +271,11 @@ class BotSortLite:
             lost_now.append(r_tracked[i])
         rest = [first[j] for j in ud]
         c3 = _iou_cost(unconfirmed, rest)
+        c3_raw = c3
         if c3.size:                                                        # boxmot's fuse_score: 1 - IoU * detection confidence
             c3 = 1.0 - (1.0 - c3) * np.array([d.conf for d in rest])[None, :]
+            if feats is not None:
+                c3 = _fuse_appearance(c3, c3_raw, unconfirmed, rest)
         m3, uu, ud3 = _assign(c3, 0.7)
         for i, j in m3:
             self._update(unconfirmed[i], rest[j], False)

@@ -113,3 +113,27 @@ def test_camera_motion_compensation_keeps_identities_under_a_fast_pan():
     with_cmc, without = ids_per_object(True), ids_per_object(False)
     assert all(len(v) == 1 for v in with_cmc.values()) and len(with_cmc) >= 9
     assert sum(len(v) for v in without.values()) > sum(len(v) for v in with_cmc.values())
+
+
+def test_appearance_fusion_decides_where_iou_cannot():
+    """BoT-SORT with_reid (oracle/tracker.py::_fuse_appearance): cost = min(IoU cost, embedding distance / 2), the embedding term only where
+    it is below appearance_thresh 0.25 and the boxes are within proximity_thresh 0.5.  Two tracks and two detections with the SAME IoU cost
+    for every pairing: the fused matrix prefers the pairs whose embeddings agree, and the assignment follows."""
+    from oracle.tracker import _assign, _fuse_appearance, _Track
+    fa, fb = np.zeros(512), np.zeros(512)
+    fa[:256] = 1.0; fb[256:] = 1.0
+    fa /= np.linalg.norm(fa); fb /= np.linalg.norm(fb)
+    ta, tb, da, db = (_Track([0, 0, 10, 10, 0.9, 0], k) for k in range(4))
+    ta.smooth_feat, tb.smooth_feat = fa, fb
+    db.curr_feat, da.curr_feat = fa, 0.98 * fb + 0.02 * fa          # detection 0 looks like track b, detection 1 like track a
+    iou = np.full((2, 2), 0.4)
+    fused = _fuse_appearance(iou, iou, [ta, tb], [da, db])
+    assert fused[0, 1] == 0.0 and fused[1, 0] < 1e-3 and fused[0, 0] == 0.4 and fused[1, 1] == 0.4
+    m, _, _ = _assign(fused, 0.8)
+    assert sorted(m) == [(0, 1), (1, 0)]
+    # thresholds: a far embedding (distance / 2 > 0.25) or a far box (IoU distance > 0.5) leaves the IoU cost untouched
+    far = np.full((2, 2), 0.6)
+    assert np.array_equal(_fuse_appearance(far, far, [ta, tb], [da, db]), far)
+    # pairs without both features keep the IoU cost
+    da.curr_feat = None
+    assert _fuse_appearance(iou, iou, [ta, tb], [da, db])[:, 0].tolist() == [0.4, 0.4]

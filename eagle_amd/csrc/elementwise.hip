@@ -61,7 +61,7 @@ __device__ __forceinline__ void split8_store(void* dst, const float* v)
 {
     half8 hi, lo;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const float s = v[i] * 16.0f; hi[i] = (_Float16)s; lo[i] = (_Float16)(s - (float)hi[i]); }
+    for (int i = 0; i < 8; ++i) { const float s = __builtin_amdgcn_fmed3f(v[i] * 16.0f, -65504.0f, 65504.0f); hi[i] = (_Float16)s; lo[i] = (_Float16)(s - (float)hi[i]); }      // saturating, as split_store4
     *(half8*)dst = hi; *((half8*)dst + 1) = lo;
 }
 

@@ -198,6 +198,15 @@ def test_conv_split_a_direct_k_split_48(shape, res, post, monkeypatch):
     assert err < F32S_TOL, f"split K-split conv error {err}"
 
 
+def test_conv_split_saturates_instead_of_overflowing():
+    """An output beyond the split format's range (|v| > 4094) clips to +-65504 / 16 instead of becoming inf (and NaN one layer later)."""
+    from eagle_amd import lib
+    x = np.full((1, 8, 8, 16), 100.0, np.float32)
+    wt = np.full((3, 3, 16, 16), 1.0, np.float32)
+    got = lib.op_conv2d(x, wt, np.zeros(16, np.float32), 1, 0, None, None, 0, lib.PREC_F32S)
+    assert np.isfinite(got).all() and got.max() == np.float32(65504.0 / 16.0) and got[0, 0, 0, 0] == np.float32(65504.0 / 16.0)
+
+
 def test_conv_split_small_and_large_magnitudes():
     """The power-of-two operand scaling keeps the lo parts out of binary16's subnormal range: weights of magnitude 1e-3 and activations of
     magnitude 1e-2 / 1e+2 give the same relative accuracy as O(1) operands."""

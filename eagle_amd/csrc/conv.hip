@@ -103,6 +103,9 @@ struct Tuned { int ks, s, cin, cout, wo, kc, nt, wx, variant; };
 static const Tuned g_tuned[] = {
 #include "conv_tuned.inc"
     {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+static const Tuned g_tuned_f32[] = {         // EAGLE_PREC_F32: tile shape only (nt, wx); the summation order, hence every bit, is the same for all rows
+#include "conv_tuned_f32.inc"
+    {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 static const Tuned g_tuned_split[] = {       // EAGLE_PREC_F32S (tools/autotune_split.py); rows of one shape are ordered best first
 #include "conv_tuned_split.inc"
     {0, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -117,6 +120,13 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
     c.wx = (wo > 16) ? 2 : 1;
     static const int nts[] = {6, 4, 3, 2, 1};
     if (precision == EAGLE_PREC_F32) {
+        static const bool tuned32 = !(getenv("EAGLE_CONV_TUNED") && atoi(getenv("EAGLE_CONV_TUNED")) == 0);
+        if (tuned32)
+            for (const Tuned& t : g_tuned_f32)
+                if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
+                    ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = 0;
+                    if (find_inst(precision, q)) return q;
+                }
         c.nt = 1;
         for (int nt : nts)
             if (cout_pad % (16 * nt) == 0) { c.nt = nt; break; }

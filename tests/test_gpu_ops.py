@@ -226,8 +226,8 @@ def test_conv_split_small_and_large_magnitudes():
 @pytest.mark.parametrize("shape,upshapes", [((2, 27, 31, 48), [(14, 16), (7, 8), (4, 4)]), ((1, 135, 240, 48), [(68, 120), (34, 60), (17, 30)]),
                                             ((3, 34, 60, 192), [(17, 30)]), ((2, 9, 33, 96), [(5, 17), (1, 1)])])
 def test_fuse_sum_parity(prec, shape, upshapes):
-    """K4 against the oracle, bit for bit in both families (the fp16 family runs the LDS-tiled form: full and partial 8 x 32 tiles, one to
-    three low-resolution operands, a 1 x 1 operand)."""
+    """K4 (one output row per workgroup, gather form) against the oracle in all three families: identical fp32 arithmetic on the stored operands,
+    one rounding (binary16 / split pair) at the store; full-size and ragged maps, one to three low-resolution operands, a 1 x 1 operand."""
     from eagle_amd import lib
     from oracle import prims as P
     n, H, W, c = shape

@@ -32,7 +32,8 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
-static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 12; }      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
+static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 13; }
+static int conv_ad_rows(const ConvConfig& c) { return (c.variant == 8 || c.variant == 10) ? 4 : c.variant == 13 ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
 static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
@@ -50,8 +51,8 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
         return conv_ws(c) ? operands + strips + 16 : std::max(operands + 16, strips);
     }
     if (precision == EAGLE_PREC_F32S && conv_ad(c)) {      // same halo ring as the fp16 kernel (16 logical channels = the 96-byte record), strips of 16 pixels x 48 channels x 4 bytes
-        const int pgn = conv_ad_wide(c) ? 1 : 2, slabs = (((4 * pgn + 2) * 34 * 96 + 1023) / 1024 + 3) / 4 * 4;
-        return (size_t)2 * slabs * 1024 + 4 * 16 * 208;
+        const int slabs = (((conv_ad_rows(c) + 2) * 34 * 96 + 1023) / 1024 + 3) / 4 * 4;
+        return (size_t)(c.variant == 13 ? 1 : 2) * slabs * 1024 + 4 * 16 * 208;       // variant 13: one halo buffer
     }
     if (precision == EAGLE_PREC_F32S) {                    // hi and lo fragment blocks per K-step; 2 * kc fp16 values per staged pixel; 4-byte outputs
         const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 2 * 4 * bn * 16 + (size_t)hh * hw * f16_ps(2 * c.kc);
@@ -64,7 +65,7 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
 size_t conv_lds_bytes(int precision, const ConvConfig& c) { return lds_bytes(precision, c); }
 int conv_tiles_per_frame(const ConvConfig& c, int ho, int wo)
 {
-    if (conv_ad(c)) return ((wo + 31) / 32) * ((ho + (conv_ad_wide(c) ? 4 : 8) - 1) / (conv_ad_wide(c) ? 4 : 8));
+    if (conv_ad(c)) return ((wo + 31) / 32) * ((ho + conv_ad_rows(c) - 1) / conv_ad_rows(c));
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     return ((wo + tw - 1) / tw) * ((ho + th - 1) / th);
 }
@@ -77,7 +78,9 @@ static const Inst g_ad_inst[] = {
     // split family: chunks of 16 logical channels (conv_ad_split.inc)
     {EAGLE_PREC_F32S, 3, 1, 16, 12, 8, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 9, nullptr},
     // split family, Cout = 48 per workgroup: tile 8 x 32, the K dimension split over wave pairs (variant 12)
-    {EAGLE_PREC_F32S, 3, 1, 16, 3, 12, nullptr}};
+    {EAGLE_PREC_F32S, 3, 1, 16, 3, 12, nullptr},
+    // the same Cout with four pixel groups (16 x 32 tile) and a single halo buffer (variant 13)
+    {EAGLE_PREC_F32S, 3, 1, 16, 3, 13, nullptr}};
 
 const Inst* conv_inst_part(int part, int* n)
 {
@@ -147,7 +150,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         //  21 K-steps per wave, too little work against the exchange, the epilogue and three barriers; kept for the tuner, off by default)
         const bool kq_on = getenv("EAGLE_CONV_KQ") && atoi(getenv("EAGLE_CONV_KQ")) != 0;      // (read per call: the parity test switches it on)
         if (sad_on && kq_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 48 == 0 && cout_pad % 96 != 0) {      // Cout = 48 (144, ...): K split over wave pairs
-            ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = 12;
+            ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = atoi(getenv("EAGLE_CONV_KQ")) == 13 ? 13 : 12;
             return q;
         }
         if (tuned_on)
@@ -382,14 +385,14 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((c.variant == 10 || c.variant == 11) ? 2 : 1) || (split && (c.stride != 1 || c.cin % 48)))
             fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32 (16 in the split family, stride 1 only), 2-byte / split output, pre_act none, post_act in {none, ReLU}");
         if (c.stride == 2) a.nchunks = 4 * c.cin / 32;      // chunks of the space-to-depth image
-        const int thh = conv_ad_wide(c) ? 4 : 8;
+        const int thh = conv_ad_rows(c);
         a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + thh - 1) / thh;
         a.gy = c.cout_pad / (c.nt * 16);
         const size_t lim = (size_t)1 << 31;
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)

@@ -18,6 +18,12 @@ ConvKernel conv_ad_split_kernel48(int n_res)           // Cout = 48: one Cout gr
     return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
 }
 
+ConvKernel conv_ad_split_kernel48sb(int n_res)         // Cout = 48: four pixel groups (16 x 32 tile), one halo buffer (variant 13)
+{
+    static const ConvKernel fn[3] = {conv_split_ad_kernel<1, 4, 0, 1, true>, conv_split_ad_kernel<1, 4, 1, 1, true>, conv_split_ad_kernel<1, 4, 2, 1, true>};
+    return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
+}
+
 ConvKernel conv_ad_split_kernel(bool wide, int n_res)
 {
     static const ConvKernel fn[2][3] = {

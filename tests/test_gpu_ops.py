@@ -180,12 +180,13 @@ def test_conv_split_a_direct(cin, cout, shape, res, post):
 
 @pytest.mark.parametrize("shape", [(3, 37, 45), (1, 16, 16), (2, 135, 240)])
 @pytest.mark.parametrize("res,post", [(True, 1), (False, 0), (2, 1)])
-def test_conv_split_a_direct_k_split_48(shape, res, post, monkeypatch):
-    """The Cout = 48 form of the split A-direct kernel (K split over wave pairs, partial accumulators exchanged through LDS; variant 12) —
-    not selected by default (measured slower than the generic kernel on 48 -> 48 @ 135 x 240), kept for the tuner and covered here."""
+@pytest.mark.parametrize("form", ["12", "13"])
+def test_conv_split_a_direct_k_split_48(shape, res, post, form, monkeypatch):
+    """The Cout = 48 forms of the split A-direct kernel: variant 12 (K split over wave pairs, partial accumulators exchanged through LDS) and
+    variant 13 (four pixel groups, 16 x 32 tile, one halo buffer).  Selected through EAGLE_CONV_KQ / the tuned table; covered here either way."""
     from eagle_amd import lib
     from oracle import prims as P
-    monkeypatch.setenv("EAGLE_CONV_KQ", "1")
+    monkeypatch.setenv("EAGLE_CONV_KQ", form)
     n, h, w = shape
     x = _rand((n, h, w, 48), 61)
     wt = _rand((3, 3, 48, 48), 62, (2.0 / (48 * 9)) ** 0.5)

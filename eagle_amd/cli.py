@@ -45,14 +45,17 @@ def main(argv=None):
     ap.add_argument("--out", default="output/synthetic")
     ap.add_argument("--detector", default="n")
     ap.add_argument("--imgsz", type=int, default=640)
-    ap.add_argument("--precision", default="f16", choices=["f16", "f32", "f32s"])
+    ap.add_argument("--precision", default="f32s", choices=["f16", "f32", "f32s"],
+                    help="f32s (default): fp32-grade results on fp16 MFMAs (what the reference's .float() path computes); f16: fastest; f32: bit-exact fp32 MFMA")
     ap.add_argument("--batch", type=int, default=10)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--num-homography", type=int, default=1, help="homography solves per second (main.py:27: 1)")
     ap.add_argument("--num-keypoint-detection", type=int, default=3, help="key-point model runs per second (main.py:27: 3)")
     ap.add_argument("--every-frame", action="store_true", help="key-points and homography on every frame (stateless configuration)")
     ap.add_argument("--calibration", action="store_true")
-    ap.add_argument("--tracker", action="store_true", help="key players by track id (BoT-SORT association, ReID off) instead of the detection index")
+    ap.add_argument("--tracker", action="store_true", help="key players by track id (BoT-SORT association) instead of the detection index")
+    ap.add_argument("--reid", action="store_true", help="with --tracker: appearance matching with OSNet-x0.25 embeddings, as the reference configures BotSort (cm.py:66-72)")
+    ap.add_argument("--reid-weights", help="with --reid: torchreid osnet_x0_25 state-dict (.pth; keys conv1.* ... fc.*, the 'reid.' prefix is added here)")
     ap.add_argument("--camera-motion", action="store_true", help="with --tracker: compensate camera motion (warp from sparse LK on a grid; boxmot uses ECC)")
     ap.add_argument("--keypoint-weights", help="HRNet state-dict (.pth as the reference loads at cm.py:58-59: keys unnormalized_model.0.* / unnormalized_model.1.*)")
     ap.add_argument("--detector-weights", help="detector checkpoint: a torch state-dict (.pth) with ultralytics key names model.N.*, or an ultralytics .pt whose 'model' entry has .state_dict()")
@@ -79,7 +82,8 @@ def main(argv=None):
         print("WARNING: running with seeded RANDOM network weights: the output has the reference's schema but no meaning", flush=True)
     model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
                             precision=a.precision, device=a.device, seed=a.seed,
-                            hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker, camera_motion=a.camera_motion)
+                            hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker, camera_motion=a.camera_motion,
+                            reid=a.reid, reid_state_dict=({("reid." + k): v for k, v in load_state_dict(a.reid_weights).items()} if a.reid_weights else None))
     t0 = time.perf_counter()
     nh, nk = (a.fps, a.fps) if a.every_frame else (a.num_homography, a.num_keypoint_detection)
     coordinates = model.get_coordinates(frames, a.fps, num_homography=nh, num_keypoint_detection=nk, verbose=False, calibration=a.calibration)

@@ -80,7 +80,9 @@ static const Inst g_ad_inst[] = {
     // split family, Cout = 48 per workgroup: tile 8 x 32, the K dimension split over wave pairs (variant 12)
     {EAGLE_PREC_F32S, 3, 1, 16, 3, 12, nullptr},
     // the same Cout with four pixel groups (16 x 32 tile) and a single halo buffer (variant 13)
-    {EAGLE_PREC_F32S, 3, 1, 16, 3, 13, nullptr}};
+    {EAGLE_PREC_F32S, 3, 1, 16, 3, 13, nullptr},
+    // split family, stride 2 over the space-to-depth image (variants 10 / 11)
+    {EAGLE_PREC_F32S, 3, 2, 16, 12, 10, nullptr}, {EAGLE_PREC_F32S, 3, 2, 16, 6, 11, nullptr}};
 
 const Inst* conv_inst_part(int part, int* n)
 {
@@ -157,7 +159,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
             for (const Tuned& t : g_tuned_split)
                 if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
                     ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = t.variant;
-                    if (conv_ad(q) && !(sad_on && plain_epilogue && cin_pad % 48 == 0)) continue;       // the A-direct kernels: ReLU / none after at most two residual adds, three chunks per loop body
+                    if (conv_ad(q) && !(sad_on && plain_epilogue && (stride == 2 ? cin_pad % 16 == 0 : cin_pad % 48 == 0))) continue;       // the A-direct kernels: ReLU / none after at most two residual adds, three chunks per loop body
                     if (find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
                 }
         if (sad_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 96 == 0) {      // A-direct, split form (three 16-channel chunks per loop body)
@@ -234,6 +236,7 @@ size_t conv_weight_elems(int precision, const ConvConfig& c)
     if (precision == EAGLE_PREC_F16 && conv_ad(c) && c.stride == 2) return (size_t)(c.cout_pad / (c.nt * 16)) * (4 * c.cin / 32) * 16 * (c.nt * 16) * 8;
     const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc;
     if (precision == EAGLE_PREC_F16) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 4 * bn * 8;
+    if (precision == EAGLE_PREC_F32S && conv_ad(c) && c.stride == 2) return (size_t)nblk * (4 * c.cin / 16) * 6 * 4 * bn * 8;      // 6 K-steps per 16-channel chunk of the space-to-depth image
     if (precision == EAGLE_PREC_F32S && conv_ad(c)) return (size_t)nblk * (c.cin / 16) * 14 * 4 * bn * 8;   // 14 K-steps per 16-channel chunk
     if (precision == EAGLE_PREC_F32S) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 2 * 4 * bn * 8;      // fp16 elements: a hi and a lo block per K-step
     return (size_t)nblk * nch * c.ks * c.ks * (c.kc / 4) * 4 * bn;
@@ -256,6 +259,27 @@ void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int c
         const float scale = std::ldexp(1.0f, sw);
         if (descale) *descale = std::ldexp(1.0f, -(sw + 4));
         _Float16* d = (_Float16*)dst;
+        if (conv_ad(c) && c.stride == 2) {
+            // stride 2: [Cout block][s2d chunk][K-step 0..5][q][BN][8].  s2d chunk -> (phase (ry, rx), 16 real channels); K-steps 0..3 = the taps' (tyy, txx)
+            // of the 2x2 kernel over the space-to-depth image, lane groups (hi g0, hi g1, hi g0, hi g1); K-steps 4, 5 = the tap' pairs (0|1), (2|3), lane
+            // groups (lo g0, lo g1 | lo g0, lo g1).  tap' row 0 is the s2d row above: only its odd phase contributes (ky = 0); row 1: ky = 1 (even phase), 2 (odd).
+            const int per_phase = c.cin / 16;
+            for (int b = 0; b < nblk; ++b)
+                for (int ch = 0; ch < 4 * per_phase; ++ch)
+                    for (int k = 0; k < 6; ++k)
+                        for (int qq = 0; qq < 4; ++qq)
+                            for (int nn = 0; nn < bn; ++nn)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int ph = ch / per_phase, c0 = (ch - ph * per_phase) * 16, ry = ph >> 1, rx = ph & 1;
+                                    const int tp = k < 4 ? k : 2 * (k - 4) + (qq >> 1), tyy = tp >> 1, txx = tp & 1;
+                                    const int ky = tyy == 0 ? (ry == 1 ? 0 : -1) : (ry == 0 ? 1 : 2), kx = txx == 0 ? (rx == 1 ? 0 : -1) : (rx == 0 ? 1 : 2);
+                                    float v = 0.f;
+                                    if (ky >= 0 && kx >= 0) v = W(ky * 3 + kx, c0 + (qq & 1) * 8 + j, b * bn + nn) * scale;
+                                    const _Float16 hi = (_Float16)v;
+                                    *d++ = k < 4 ? hi : (_Float16)(v - (float)hi);
+                                }
+            return;
+        }
         if (conv_ad(c)) {
             // A-direct form: [Cout block][16-channel chunk][K-step 0..13][q][BN][8].  K-steps 0..8 = taps, lane groups (hi g0, hi g1, hi g0, hi g1):
             // against the record slots (hi g0, hi g1, lo g0, lo g1) that is hi*hi + hi*lo.  K-steps 9..13 = tap pairs (0|1, 2|3, 4|5, 6|7, 8|-),
@@ -382,9 +406,9 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
         const bool split = precision == EAGLE_PREC_F32S;
-        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((c.variant == 10 || c.variant == 11) ? 2 : 1) || (split && (c.stride != 1 || c.cin % 48)))
+        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((c.variant == 10 || c.variant == 11) ? 2 : 1) || (split && c.stride == 1 && c.cin % 48) || (split && c.stride == 2 && c.cin % 16))
             fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32 (16 in the split family, stride 1 only), 2-byte / split output, pre_act none, post_act in {none, ReLU}");
-        if (c.stride == 2) a.nchunks = 4 * c.cin / 32;      // chunks of the space-to-depth image
+        if (c.stride == 2) a.nchunks = split ? 4 * c.cin / 16 : 4 * c.cin / 32;      // chunks of the space-to-depth image
         const int thh = conv_ad_rows(c);
         a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + thh - 1) / thh;
         a.gy = c.cout_pad / (c.nt * 16);
@@ -392,7 +416,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)

@@ -24,6 +24,14 @@ ConvKernel conv_ad_split_kernel48sb(int n_res)         // Cout = 48: four pixel 
     return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
 }
 
+ConvKernel conv_ad_split_kernel_s2(bool wide, int n_res)      // stride 2 over the space-to-depth image (variants 10 / 11)
+{
+    static const ConvKernel fn[2][3] = {
+        {conv_split_ad_kernel<2, 2, 0, 1, false, true>, conv_split_ad_kernel<2, 2, 1, 1, false, true>, conv_split_ad_kernel<2, 2, 2, 1, false, true>},
+        {conv_split_ad_kernel<4, 1, 0, 1, false, true>, conv_split_ad_kernel<4, 1, 1, 1, false, true>, conv_split_ad_kernel<4, 1, 2, 1, false, true>}};
+    return fn[wide ? 1 : 0][n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
+}
+
 ConvKernel conv_ad_split_kernel(bool wide, int n_res)
 {
     static const ConvKernel fn[2][3] = {

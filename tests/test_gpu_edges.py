@@ -236,3 +236,63 @@ def test_bench_command_path_at_eight_ranks_on_one_gpu():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 8 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["frames_total"] == 8 * 2 * 4 and res["config"]["gather"] == "dist"
+
+
+def test_geometry_bit_identical_while_another_handle_runs_the_fp16_networks():
+    """VERDICT r2 task 9: the concurrent-handle check of the LK kernel, extended to the geometry kernel (`post_kernel`: threshold / dedup / line
+    synthesis / RANSAC / DLT / LM / projection, all fp64 and bit-identical to the oracle when run alone).  `eagle_op_find_homography` — the same
+    device code — on ten cameras in a loop WHILE a second handle keeps the GPU busy with the fp16 (f16-MFMA) networks on another thread: every H
+    and every inlier mask must equal the solo result bit for bit, and the busy handle's own records must not change either."""
+    import threading
+    from eagle_amd import lib, synth, weights
+    from eagle_amd.coordinate_model import CoordinateModel
+    from eagle_amd.pitch import LANDMARKS, on_plane_mask
+    hs, ys = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("n", 0)
+
+    def camera_points(seed, noise, n_out):
+        rng = np.random.default_rng(seed)
+        Hm = synth.camera(seed, 10 * seed)
+        m = on_plane_mask()
+        world = np.array([[x, y] for (i, _, x, y, z) in LANDMARKS if m[i]], np.float64)
+        img = synth.project(Hm, world)
+        keep = (img[:, 0] >= 0) & (img[:, 0] < 1280) & (img[:, 1] >= 0) & (img[:, 1] < 720)
+        img, world = img[keep], world[keep]
+        img = np.floor(img + rng.normal(0, noise, img.shape))
+        for k in rng.choice(len(img), size=min(n_out, len(img)), replace=False):
+            img[k] = rng.uniform(0, 700, 2)
+        return img.astype(np.float32), world.astype(np.float32)
+
+    cases = [camera_points(s, nz, no) for s, nz, no in [(0, 0.0, 0), (1, 0.7, 0), (2, 0.5, 4), (3, 1.0, 7), (4, 0.0, 2), (5, 2.0, 14), (6, 0.3, 18), (7, 1.5, 3), (8, 0.2, 9), (9, 0.9, 1)]]
+    solo = [lib.op_find_homography(i, w, 5.0) for i, w in cases]
+    co = CoordinateModel(precision="f16", batch=8, hrnet_state_dict=hs, detector_state_dict=ys)
+    busy_frames = synth.clip(0, 8)
+    stop, batches, err = [False], [0], []
+
+    def busy():
+        try:
+            ref = co.process_records(busy_frames)
+            while not stop[0]:
+                r = co.process_records(busy_frames)
+                batches[0] += 1
+                if any(r[f].tobytes() != ref[f].tobytes() for f in r.dtype.names):
+                    err.append("the co-running fp16 path changed its own records")
+        except Exception as e:                       # pragma: no cover
+            err.append(repr(e))
+
+    t = threading.Thread(target=busy)
+    t.start()
+    try:
+        rounds = 0
+        while batches[0] < 10 and not err and rounds < 2000:
+            for (i, w), (H0, m0) in zip(cases, solo):
+                H1, m1 = lib.op_find_homography(i, w, 5.0)
+                assert (H0 is None) == (H1 is None)
+                if H0 is not None:
+                    assert np.array_equal(H0, H1) and np.array_equal(m0, m1), "geometry kernel result changed next to the fp16 networks"
+            rounds += 1
+    finally:
+        stop[0] = True
+        t.join()
+        co.handle.close()
+    assert not err, err
+    assert batches[0] >= 10 and rounds >= 1

@@ -356,7 +356,7 @@ def _f32s_record_parity(rec, oref, aux, tag, frame_hw, conf_tol=5e-6, box_tol=2e
     — a float that sits within 1e-3 of an integer before truncation, and an arg-max between two heat-map values closer than 2e-6 — and each
     occurrence is counted and returned so that the summary line shows them.
     Float tolerances are set from the spread between the oracle's OWN two fp32 backends (exact fmaf chain vs torch / oneDNN, i.e. two legitimate
-    fp32 summation orders; tools/probes/fp32_order_noise.py): cfg 2 — confidences 2.4e-6, heat-map scores 2.4e-7, logits 8.8e-7 relative, and
+    fp32 summation orders; tests/golden/fp32_order_noise.py): cfg 2 — confidences 2.4e-6, heat-map scores 2.4e-7, logits 8.8e-7 relative, and
     one swapped pair of detection ids; cfg 3 (yolov8l, 103 convolutions deep) — confidences 2.0e-5 .. 3.0e-5 over the three test frames, boxes
     5.3e-3 px.  conf_tol / box_tol are 2x those.  The family's measured deviations (printed) equal the fp32 spread on cfg 2 (2.5e-6) and reach
     1.8x it on the deepest network (4.3e-5 on one cfg-3 frame: 103 layers of 22-bit tensor storage against fp32's 24)."""

@@ -150,9 +150,15 @@ template <> struct Vec<SplitT> {
     __device__ __forceinline__ void load(const void* p, size_t e)
     {
         const half8 hi = *(const half8*)((const char*)p + e * 4), lo = *(const half8*)((const char*)p + e * 4 + 16);
-        for (int i = 0; i < 8; ++i) v[i] = ((float)hi[i] + (float)lo[i]) * 0.0625f;
+        for (int i = 0; i < 8; ++i) v[i] = (float)hi[i] + (float)lo[i];      // = 16 x the value: every user of this type (bilinear sum, max, copy,
+    }                                                                          // ReLU) is linear or monotone, and scaling by 2^4 commutes with fp32 rounding
+    __device__ __forceinline__ void store(void* p, size_t e) const
+    {
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float s = __builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f); hi[i] = (_Float16)s; lo[i] = (_Float16)(s - (float)hi[i]); }
+        *(half8*)((char*)p + e * 4) = hi; *((half8*)((char*)p + e * 4) + 1) = lo;
     }
-    __device__ __forceinline__ void store(void* p, size_t e) const { split8_store((char*)p + e * 4, v); }
 };
 template <> struct Vec<float> {
     static constexpr int N = 4;

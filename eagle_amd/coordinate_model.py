@@ -18,7 +18,7 @@ from .pitch import INTERSECTION_TO_PITCH_POINTS
 
 class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
-                 detector="n", det_imgsz=640, batch=8, precision="f16", device=0, hrnet_state_dict=None,
+                 detector="n", det_imgsz=640, batch=8, precision="f32s", device=0, hrnet_state_dict=None,
                  detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False, detector_precision=None,
                  reid=False, reid_state_dict=None):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf

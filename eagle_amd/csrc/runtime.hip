@@ -1064,7 +1064,7 @@ int eagle_default_config(EagleConfig* cfg)
     if (!cfg) return EAGLE_E_INVALID;
     memset(cfg, 0, sizeof(*cfg));
     cfg->device = 0; cfg->frame_h = 720; cfg->frame_w = 1280;
-    cfg->det_variant = EAGLE_DET_N; cfg->det_imgsz = 640; cfg->batch = 8; cfg->precision = EAGLE_PREC_F16;
+    cfg->det_variant = EAGLE_DET_N; cfg->det_imgsz = 640; cfg->batch = 8; cfg->precision = EAGLE_PREC_F32S;      // fp32-grade results by default (the reference computes in fp32)
     cfg->keypoint_conf = 0.3; cfg->detector_conf = 0.35; cfg->ransac_thresh = 5.0;
     cfg->detector_floor = 0.15f; cfg->nms_iou = 0.7f;
     cfg->ransac_max_iters = 2000; cfg->lm_iters = 10; cfg->use_graph = 0;

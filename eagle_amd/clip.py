@@ -10,11 +10,12 @@ import numpy as np
 from . import lib
 
 
-def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None, motion=None):
+def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=False, stats=None, keypoint_source=None, motion=None, motion_fn=None):
     """h: lib.Handle; dptr: n BGR frames resident in HBM.  -> RESULT_DTYPE[n].
     keypoint_source(i) -> FLOWKP_DTYPE array: an external key-point detector replacing HRNet (what detect_keypoints(frames[i])
     would return, in dict order); the parity tests use it to replay the reference's canned detections.
-    motion: a list that receives the [n, 6] camera motions of the clip (eagle_clip_motion) while the session is open (tracker CMC)."""
+    motion: a list that receives the [n, 6] camera motions of the clip while the session is open (tracker CMC): motion_fn(n) if given
+    (CoordinateModel's configured estimator), else eagle_clip_motion."""
     detected = []
 
     def detect(first, stride=1, count=1):
@@ -46,7 +47,7 @@ def run_clip(h, dptr, n, keypoint_interval, homography_interval, calibration=Fal
             stalled = h.clip_run(stalled, n, keypoint_interval, homography_interval, calibration, wait=True)
         recs = h.clip_fetch(n)
         if motion is not None:
-            motion.append(h.clip_motion(0, n))
+            motion.append(motion_fn(n) if motion_fn is not None else h.clip_motion(0, n))
     finally:
         h.clip_close()
     if stats is not None:

@@ -6,9 +6,10 @@ Same constructor keywords and method names as the reference: ``CoordinateModel(k
 ``detect_objects(frame)``, ``detect_keypoints(frame)``.  ``get_coordinates`` covers every key-point / homography cadence of
 the reference (optical-flow propagation between detections, first-frame search, on-demand detection, calibration:
 cm.py:188-416).  ``tracker=True`` keys Player / Goalkeeper entries by track id like the reference does through boxmot's BotSort
-(cm.py:574-596): the library's BoT-SORT motion / IoU association with ReID and camera-motion compensation off (include/eagle.h,
-eagle_track_*; stated deviations); ``camera_motion=True`` adds BoT-SORT's camera-motion compensation, the warp estimated from sparse LK on a
-grid (eagle_clip_motion) instead of boxmot's ECC.  ``tracker=False`` (default) is the reference's detection-index fallback (cm.py:598-627), the
+(cm.py:574-596): the library's BoT-SORT association (include/eagle.h, eagle_track_*); ``reid=True`` adds the appearance branch and
+``camera_motion="ecc"`` boxmot's default camera-motion compensation (ECC on the 0.15-scale gray frame, eagle_clip_motion_ecc) — together the
+configuration the reference constructs at cm.py:66-72; ``camera_motion=True`` / ``"sparse"`` is BoT-SORT's sparse-optical-flow alternative on a
+fixed grid (eagle_clip_motion).  ``tracker=False`` (default) is the reference's detection-index fallback (cm.py:598-627), the
 stateless configuration of SURVEY §8a."""
 import numpy as np
 
@@ -23,7 +24,9 @@ class CoordinateModel:
                  reid=False, reid_state_dict=None):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
-        self.camera_motion = camera_motion
+        if camera_motion not in (False, True, None, "sparse", "ecc"):
+            raise ValueError("camera_motion must be False, True / 'sparse' or 'ecc'")
+        self.camera_motion = "sparse" if camera_motion is True else (camera_motion or False)
         self.reid = bool(reid) and tracker      # appearance matching inside the tracker (the reference's BotSort has it on: cm.py:66-72)
         self._tracker_open = False           # the reference builds ONE BotSort in __init__ (cm.py:66-72): ids keep counting across get_coordinates calls
         self.batch = batch
@@ -125,6 +128,12 @@ class CoordinateModel:
             self.handle.track_frames(recs, warps)
         return recs
 
+    def _session_motion(self, n):
+        """camera motions of the open clip session, by the configured estimator"""
+        if self.camera_motion == "ecc":
+            return self.handle.clip_motion_ecc(0, n, carry=True)
+        return self.handle.clip_motion(0, n)
+
     def _clip_motion(self, frames):
         """[n, 6] camera motions of a clip that is not in a clip session yet: gray pyramids + sparse LK on the GPU (eagle_clip_open / _motion)."""
         frames = np.ascontiguousarray(frames, np.uint8)
@@ -132,7 +141,7 @@ class CoordinateModel:
         try:
             self.handle.clip_open(d, len(frames))
             try:
-                return self.handle.clip_motion(0, len(frames))
+                return self._session_motion(len(frames))
             finally:
                 self.handle.clip_close()
         finally:
@@ -145,7 +154,8 @@ class CoordinateModel:
             return np.zeros(0, lib.RESULT_DTYPE)
         d = self.handle.upload(frames)
         try:
-            return clip.run_clip(self.handle, d, len(frames), keypoint_interval, homography_interval, calibration, stats, keypoint_source, motion)
+            return clip.run_clip(self.handle, d, len(frames), keypoint_interval, homography_interval, calibration, stats, keypoint_source, motion,
+                                 motion_fn=self._session_motion)
         finally:
             self.handle.free(d)
 

@@ -148,6 +148,11 @@ struct ChainState {
 };
 void gray_pyramid_launch(const uint8_t* d_bgr, int n, int h, int w, uint8_t* g0, uint8_t* g1, uint8_t* g2, hipStream_t s);
 void lk_launch(const ClipView& cv, int src_frame, int dst_frame, ChainState* st, const MemList* mem, int kint, hipStream_t s);
+// ---- ECC camera motion (ecc.hip, K17) ---------------------------------------------------------------------------------------------
+struct EccResult { int ok, iters; double rho; float M[6]; };       // M: 2 x 3 warp in the 0.15-scale image's pixels (template -> image)
+void ecc_small_launch(const uint8_t* gray, uint8_t* small, int n, int h, int w, int dh, int dw, hipStream_t s);
+// pairs[k] = (template frame or -1 = `carry`, image frame), indices into `small` ([n, h, w] u8)
+void ecc_launch(const uint8_t* small, const uint8_t* carry, const int2* pairs, int n_pairs, EccResult* out, int h, int w, int max_iter, double eps, hipStream_t s);
 // ---- team colours (teams.hip, K15) ----------------------------------------------------------------------------------------------
 void team_colors_launch(const uint8_t* d_bgr, int n_frames, int fh, int fw, const EagleCrop* d_crops, int n_crops, int* d_counts, hipStream_t s);
 

@@ -203,7 +203,12 @@ struct EagleHandle {
         int* h_tail = nullptr;             // pinned: {stalled, error} read-back, [2] = the constant -1
         MemList* h_mem = nullptr;          // pinned staging of eagle_clip_get/set_keypoints
         hipEvent_t ev_gray = nullptr, ev_det = nullptr, ev_kp = nullptr, ev_loop = nullptr;
+        uint8_t* ecc_small = nullptr;      // K17: [n, ecc_h, ecc_w] 0.15-scale gray images (built on the first eagle_clip_motion_ecc call)
+        int ecc_h = 0, ecc_w = 0;
+        int2* ecc_pairs = nullptr; eagle::EccResult* ecc_out = nullptr;   // device, n entries
     } clip;
+    // boxmot's ECC object lives as long as the tracker: the last template survives the clip (carried by eagle_clip_motion_ecc, reset by eagle_track_open)
+    uint8_t* ecc_prev = nullptr; int ecc_prev_h = 0, ecc_prev_w = 0; bool ecc_has_prev = false;
     // comm
     void* rccl = nullptr; void* comm = nullptr; int rank = 0, world = 1;
 };
@@ -884,6 +889,9 @@ static void clip_close(EagleHandle* h)
     if (c.h_zero) (void)hipHostFree(c.h_zero);
     if (c.h_tail) (void)hipHostFree(c.h_tail);
     if (c.h_mem) (void)hipHostFree(c.h_mem);
+    if (c.ecc_small) (void)hipFree(c.ecc_small);
+    if (c.ecc_pairs) (void)hipFree(c.ecc_pairs);
+    if (c.ecc_out) (void)hipFree(c.ecc_out);
     for (hipEvent_t e : {c.ev_gray, c.ev_det, c.ev_kp, c.ev_loop}) if (e) (void)hipEventDestroy(e);
     c = EagleHandle::Clip();
 }
@@ -1120,6 +1128,7 @@ void eagle_destroy(EagleHandle* h)
     for (auto& e : h->conv_ev) (void)hipEventDestroy(e);
     for (auto& e : h->span_pool) (void)hipEventDestroy(e);
     h->hr.reset(); h->yo.reset(); h->misc.reset(); h->reid.reset();
+    if (h->ecc_prev) (void)hipFree(h->ecc_prev);
     if (h->reid_crops_h) (void)hipHostFree(h->reid_crops_h);
     if (h->reid_feats_h) (void)hipHostFree(h->reid_feats_h);
     if (h->s_main) (void)hipStreamDestroy(h->s_main);
@@ -1312,6 +1321,7 @@ int eagle_track_open(EagleHandle* h, const EagleTrackParams* params)
     API_BEGIN
     if (h->tracker) eagle::tracker_destroy(h->tracker);
     h->tracker = eagle::tracker_create(params);
+    h->ecc_has_prev = false;                              // a new BotSort builds a new ECC estimator
     API_END(h)
 }
 
@@ -1472,6 +1482,75 @@ int eagle_clip_motion(EagleHandle* h, int first, int count, double* warps)
         for (int k = 0; k < NP; ++k)
             if (z.lk_status[k] == 1) { p0[2 * m] = z.prev[k].x; p0[2 * m + 1] = z.prev[k].y; p1[2 * m] = z.lk_next[2 * k]; p1[2 * m + 1] = z.lk_next[2 * k + 1]; ++m; }
         eagle::similarity_ransac(p0, p1, m, W);
+    }
+    API_END(h)
+}
+
+int eagle_clip_motion_ecc(EagleHandle* h, int first, int count, int carry, double* warps, int* ok_out)
+{
+    CLIP_CHECK(h, h->clip.open && first >= 0 && count >= 0 && first + count <= h->clip.cv.n && (warps || count == 0), "eagle_clip_motion_ecc: bad arguments")
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(h->cfg.device));
+    EagleHandle::Clip& c = h->clip;
+    constexpr double SCALE = 0.15, EPS = 1e-5; constexpr int MAX_ITER = 100;      // boxmot ECC(): scale 0.15, (EPS | COUNT, 100, 1e-5)
+    const int dh = (int)lrint(c.cv.h * SCALE), dw = (int)lrint(c.cv.w * SCALE), n = c.cv.n;
+    if (dh < 4 || dw < 4) fail(EAGLE_E_INVALID, "eagle_clip_motion_ecc: frame too small for the 0.15-scale alignment");
+    hipStream_t sm = h->s_main;
+    if (!c.ecc_small && n > 0) {
+        HIP_CHECK(hipMalloc(&c.ecc_small, (size_t)n * dh * dw));
+        HIP_CHECK(hipMalloc(&c.ecc_pairs, sizeof(int2) * n));
+        HIP_CHECK(hipMalloc(&c.ecc_out, sizeof(eagle::EccResult) * n));
+        c.ecc_h = dh; c.ecc_w = dw;
+        HIP_CHECK(hipStreamWaitEvent(sm, c.ev_gray, 0));
+        eagle::ecc_small_launch(c.g[0], c.ecc_small, n, c.cv.h, c.cv.w, dh, dw, sm);
+    }
+    const bool use_carry = carry && h->ecc_has_prev && h->ecc_prev_h == dh && h->ecc_prev_w == dw;
+    // every adjacent pair at once; pairs behind a failed alignment (boxmot keeps the old template) are re-run one by one below
+    std::vector<int2> pairs; std::vector<int> slot(count, -1);
+    for (int i = 0; i < count; ++i) {
+        const int f = first + i;
+        if (f > 0) { slot[i] = (int)pairs.size(); pairs.push_back(make_int2(f - 1, f)); }
+        else if (use_carry) { slot[i] = (int)pairs.size(); pairs.push_back(make_int2(-1, f)); }
+    }
+    std::vector<eagle::EccResult> res(pairs.size());
+    if (!pairs.empty()) {
+        HIP_CHECK(hipMemcpyAsync(c.ecc_pairs, pairs.data(), sizeof(int2) * pairs.size(), hipMemcpyHostToDevice, sm));
+        eagle::ecc_launch(c.ecc_small, h->ecc_prev, c.ecc_pairs, (int)pairs.size(), c.ecc_out, dh, dw, MAX_ITER, EPS, sm);
+        HIP_CHECK(hipMemcpyAsync(res.data(), c.ecc_out, sizeof(eagle::EccResult) * pairs.size(), hipMemcpyDeviceToHost, sm));
+        HIP_CHECK(hipStreamSynchronize(sm));
+    }
+    constexpr int NONE = -2;
+    int prev = first > 0 ? first - 1 : (use_carry ? -1 : NONE);
+    for (int i = 0; i < count; ++i) {
+        const int f = first + i;
+        double* W = warps + (size_t)i * 6;
+        W[0] = 1; W[1] = 0; W[2] = 0; W[3] = 0; W[4] = 1; W[5] = 0;
+        if (ok_out) ok_out[i] = 1;
+        if (prev == NONE) { prev = f; continue; }        // the estimator's first frame: identity, becomes the template
+        eagle::EccResult r;
+        if (slot[i] >= 0 && pairs[slot[i]].x == prev) r = res[slot[i]];
+        else {
+            const int2 one = make_int2(prev, f);
+            HIP_CHECK(hipMemcpyAsync(c.ecc_pairs, &one, sizeof(one), hipMemcpyHostToDevice, sm));
+            eagle::ecc_launch(c.ecc_small, h->ecc_prev, c.ecc_pairs, 1, c.ecc_out, dh, dw, MAX_ITER, EPS, sm);
+            HIP_CHECK(hipMemcpyAsync(&r, c.ecc_out, sizeof(r), hipMemcpyDeviceToHost, sm));
+            HIP_CHECK(hipStreamSynchronize(sm));
+        }
+        if (!r.ok) { if (ok_out) ok_out[i] = 0; continue; }     // cv2 raised: identity, template unchanged
+        for (int k = 0; k < 6; ++k) W[k] = (double)r.M[k];
+        W[2] = (double)(float)((double)r.M[2] / SCALE); W[5] = (double)(float)((double)r.M[5] / SCALE);   // warp_matrix[i, 2] /= self.scale
+        prev = f;
+    }
+    if (carry && prev != NONE && prev != -1) {
+        if (!h->ecc_prev || h->ecc_prev_h != dh || h->ecc_prev_w != dw) {
+            if (h->ecc_prev) HIP_CHECK(hipFree(h->ecc_prev));
+            h->ecc_prev = nullptr;
+            HIP_CHECK(hipMalloc(&h->ecc_prev, (size_t)dh * dw));
+            h->ecc_prev_h = dh; h->ecc_prev_w = dw;
+        }
+        HIP_CHECK(hipMemcpyAsync(h->ecc_prev, c.ecc_small + (size_t)prev * dh * dw, (size_t)dh * dw, hipMemcpyDeviceToDevice, sm));
+        HIP_CHECK(hipStreamSynchronize(sm));
+        h->ecc_has_prev = true;
     }
     API_END(h)
 }

@@ -112,6 +112,7 @@ def load():
     L.eagle_track_frames.argtypes = [vp, vp, i32]
     L.eagle_track_frames_cmc.argtypes = [vp, vp, i32, C.POINTER(C.c_double)]
     L.eagle_clip_motion.argtypes = [vp, i32, i32, C.POINTER(C.c_double)]
+    L.eagle_clip_motion_ecc.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i32)]
     L.eagle_reid_features.argtypes = [vp, vp, i32, vp, i32, fp]
     L.eagle_track_frames_reid.argtypes = [vp, vp, i32, C.POINTER(C.c_double), fp, C.POINTER(i32), C.POINTER(i32)]
     _lib = L
@@ -123,7 +124,7 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
            "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
-           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_track_frames_cmc", "eagle_clip_motion", "eagle_team_colors",
+           "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_track_frames_cmc", "eagle_clip_motion_ecc", "eagle_clip_motion", "eagle_team_colors",
            "eagle_reid_features", "eagle_track_frames_reid"]
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
@@ -346,6 +347,15 @@ class Handle:
         w = np.zeros((max(count, 0), 6), np.float64)
         self._check(self.L.eagle_clip_motion(self._h, first, count, w.ctypes.data_as(C.POINTER(C.c_double))), "clip_motion")
         return w
+
+    def clip_motion_ecc(self, first, count, carry=False, return_ok=False):
+        """boxmot's default camera-motion estimator (ECC on the 0.15-scale gray frame): [count, 6] float64 warps like clip_motion; carry=True
+        keeps the estimator's template across clips (the tracker's lifetime; track_open forgets it)."""
+        w = np.zeros((max(count, 0), 6), np.float64)
+        ok = np.zeros(max(count, 0), np.int32)
+        self._check(self.L.eagle_clip_motion_ecc(self._h, first, count, int(bool(carry)), w.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 ok.ctypes.data_as(C.POINTER(C.c_int32))), "clip_motion_ecc")
+        return (w, ok) if return_ok else w
 
     def set_profiling(self, on):
         self._check(self.L.eagle_set_profiling(self._h, int(on)), "set_profiling")

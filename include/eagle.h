@@ -178,7 +178,7 @@ int eagle_clip_close(EagleHandle* h);
 
 /* ---- track identities: self.tracker.update(dets, frame) of cm.py:66-72, 574-596 -----------------------------------
  * BoT-SORT's motion / IoU association (constant-velocity Kalman filter, high / low confidence sets, three assignments, life cycle);
- * appearance ReID is off and camera-motion compensation uses sparse LK instead of ECC (eagle_clip_motion below; stated deviations).  eagle_track_frames walks n records of ONE
+ * appearance and camera-motion compensation are separate entry points below (eagle_reid_features, eagle_clip_motion_ecc / eagle_clip_motion).  eagle_track_frames walks n records of ONE
  * clip in frame order (call it chunk after chunk; eagle_track_open starts a new clip): Player / Goalkeeper entries become keyed by
  * track id with the filter's boxes and feet (cm.py:577-596; frames on which the tracker reports no player keep the detection-index
  * fallback of cm.py:598-616), then the pitch coordinates of the moved foot points are recomputed on the GPU with each record's H. */
@@ -194,6 +194,13 @@ int eagle_track_frames(EagleHandle* h, EagleFrameResult* recs, int n);
  * eagle_clip_motion: needs an open clip session (eagle_clip_open); warps[6 * i .. +5] = row-major 2 x 3 warp of frame first+i-1 -> first+i
  * (identity for clip frame 0).  eagle_track_frames_cmc: as eagle_track_frames, applying warps[6 * i] to all track states before frame i is associated. */
 int eagle_clip_motion(EagleHandle* h, int first, int count, double* warps);
+/* boxmot's default estimator (cmc_method "ecc", what the reference's BotSort(...) of cm.py:66-72 runs on the frame passed at cm.py:577):
+ * gray -> cv2.resize(fx = fy = 0.15) -> cv2.findTransformECC(prev, cur, MOTION_EUCLIDEAN, 100 iterations / 1e-5), translation rescaled by 1 / 0.15;
+ * a failed alignment (cv2 raises: lambda_d <= 0 or NaN correlation) yields the identity and keeps the OLD template, as boxmot does.  Same warps
+ * layout as eagle_clip_motion; ok[i] (may be NULL) = 0 where the alignment of frame first+i failed.  carry != 0: the estimator's template
+ * survives the clip like boxmot's ECC object survives inside the tracker — clip frame 0 is aligned to the last template of the previous call
+ * (eagle_track_open forgets it).  Restated from the published algorithm (oracle/ecc.py); cv2 / boxmot absent: parity unpinned. */
+int eagle_clip_motion_ecc(EagleHandle* h, int first, int count, int carry, double* warps, int* ok);
 int eagle_track_frames_cmc(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps /* NULL: none */);
 /* Appearance (BoT-SORT with_reid, the reference's configuration: cm.py:66-72 builds BotSort with osnet_x0_25 ReID weights and passes the frame at
  * cm.py:577).  eagle_reid_features: OSNet-x0.25 embeddings (EAGLE_REID_DIM floats each) of crops frame[y1:y2, x1:x2] of a clip resident in HBM,

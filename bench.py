@@ -221,6 +221,22 @@ def main():
                    "note": "stateful reference cadence (cm.py:205-206): detector on every frame, HRNet on hrnet_frames of each clip's frames, LK flow + loop body per frame; one clip per GPU"}
         log(f"reference cadence @{a.cadence} fps: {cadence['value']} frames/s ({cadence['hrnet_frames']} HRNet frames)")
 
+    cmc = None
+    if extras:                                           # tracker side stage: boxmot's default camera-motion estimator over the whole clip (K17)
+        h.clip_open(d_clip, min(n_local, 4)); h.clip_motion_ecc(0, min(n_local, 4)); h.clip_close()      # warm-up
+        t1 = time.perf_counter()
+        h.clip_open(d_clip, n_local)
+        wm, okm = h.clip_motion_ecc(0, n_local, return_ok=True)
+        dte = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        h.clip_motion_ecc(0, n_local)                    # the 0.15-scale images exist now: the alignment launch + read-back alone
+        dtk = time.perf_counter() - t1
+        h.clip_close()
+        cmc = {"value": round(n_local / dte, 1), "unit": "frames/s", "alignment_only": round(n_local / dtk, 1), "failed_alignments": int((okm == 0).sum()),
+               "note": "eagle_clip_motion_ecc on the resident clip: gray pyramids + 0.15-scale images + one ECC workgroup per frame pair (<= 100 iterations inside the launch); "
+                       "runs once per clip when track ids with camera-motion compensation are asked for, not part of value"}
+        log(f"camera motion (ECC): {cmc['value']} frames/s incl. gray images, {cmc['alignment_only']} alignment only")
+
     # dominant kernel = the implicit-GEMM convolution family: per-launch HIP events on the launch stream
     def profile(hh, dptr, nb, prof_steps=2):
         hh.set_profiling(1)
@@ -371,6 +387,8 @@ def main():
             res["reference_cadence"] = cadence
         if pcie is not None:
             res["pcie_inclusive"] = pcie
+        if cmc is not None:
+            res["camera_motion_ecc"] = cmc
         if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only (the measurement contract)
             res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())), variant=a.detector, imgsz=a.imgsz)
             # (all 256 hardware threads of the GPU box were tried once: torch-CPU convolutions collapse to 0.004 frames/s, 247 s for one

@@ -56,7 +56,9 @@ def main(argv=None):
     ap.add_argument("--tracker", action="store_true", help="key players by track id (BoT-SORT association) instead of the detection index")
     ap.add_argument("--reid", action="store_true", help="with --tracker: appearance matching with OSNet-x0.25 embeddings, as the reference configures BotSort (cm.py:66-72)")
     ap.add_argument("--reid-weights", help="with --reid: torchreid osnet_x0_25 state-dict (.pth; keys conv1.* ... fc.*, the 'reid.' prefix is added here)")
-    ap.add_argument("--camera-motion", action="store_true", help="with --tracker: compensate camera motion (warp from sparse LK on a grid; boxmot uses ECC)")
+    ap.add_argument("--camera-motion", nargs="?", const="ecc", default=None, choices=["ecc", "sparse"],
+                    help="with --tracker: compensate camera motion; 'ecc' (default when the flag is given) is boxmot's default estimator, i.e. the reference's "
+                         "configuration; 'sparse' = BoT-SORT's sparse-optical-flow alternative on a fixed grid")
     ap.add_argument("--keypoint-weights", help="HRNet state-dict (.pth as the reference loads at cm.py:58-59: keys unnormalized_model.0.* / unnormalized_model.1.*)")
     ap.add_argument("--detector-weights", help="detector checkpoint: a torch state-dict (.pth) with ultralytics key names model.N.*, or an ultralytics .pt whose 'model' entry has .state_dict()")
     ap.add_argument("--synthetic-weights", action="store_true", help="run with seeded RANDOM networks (plumbing / benchmarking only: the coordinates are meaningless)")
@@ -82,7 +84,7 @@ def main(argv=None):
         print("WARNING: running with seeded RANDOM network weights: the output has the reference's schema but no meaning", flush=True)
     model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
                             precision=a.precision, device=a.device, seed=a.seed,
-                            hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker, camera_motion=a.camera_motion,
+                            hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker, camera_motion=a.camera_motion or False,
                             reid=a.reid, reid_state_dict=({("reid." + k): v for k, v in load_state_dict(a.reid_weights).items()} if a.reid_weights else None))
     t0 = time.perf_counter()
     nh, nk = (a.fps, a.fps) if a.every_frame else (a.num_homography, a.num_keypoint_detection)

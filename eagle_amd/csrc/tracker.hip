@@ -1,8 +1,9 @@
 // K14 — track identities: what the reference gets from boxmot's BotSort behind `self.tracker.update(dets, frame)`
 // (eagle/models/coordinate_model.py:66-72, 574-596).  BoT-SORT's motion / IoU association (Aharon et al. 2022, on ByteTrack's two-stage
 // scheme): constant-velocity Kalman filter on (cx, cy, w, h), high / low confidence detection sets, three linear assignments with cost
-// limits, track life cycle.  Stated deviations from the reference's configuration: appearance ReID (OSNet) and ECC camera-motion
-// compensation are off; the same restatement is oracle/tracker.py, which the tests compare this code with.
+// limits, track life cycle, BoT-SORT's IoU / appearance fusion with the per-track feature EMA (embeddings from K16, reid.hip) and the camera-motion
+// warp applied to the track states before association (warps from K17, ecc.hip = boxmot's default estimator, or from the sparse-LK grid);
+// the same restatement is oracle/tracker.py, which the tests compare this code with.
 //
 // Why this stage runs on the HOST side of the library (native C++, not a kernel): it is a strictly sequential recurrence over the
 // frames of a clip on <= 300 boxes — per frame a handful of 8x8 Kalman updates and one ~30x30 assignment, tens of microseconds on

@@ -5,11 +5,11 @@ BoT-SORT track association as the reference runs it behind ``self.tracker.update
 this image: restated from the published algorithm (Aharon et al. 2022; ByteTrack's two-stage association), PARITY UNPINNED).
 
 Appearance (``with_reid=True``, the reference's configuration): ``update(..., feats=)`` takes the OSNet embeddings of the high-confidence
-detections (oracle/reid.py) and fuses them as BoT-SORT does.  Stated deviation: camera-motion compensation: boxmot's default is ECC on the gray frame (cv2, absent); here the warp is a similarity transform
-estimated from a fixed 8 x 6 grid of points tracked by the pyramidal LK of the key-point cadence (``camera_motion``: the same K12 kernel on the
-GPU side), RANSAC over point pairs + least squares on the consensus set — BoT-SORT's own "sparseOptFlow" alternative with a fixed grid instead
-of a corner detector.  The warp is applied as BoT-SORT's ``multi_gmc`` does (means and covariances of all pooled and unconfirmed tracks, after
-the prediction step).  What remains is the motion / IoU part of BoT-SORT exactly as published:
+detections (oracle/reid.py) and fuses them as BoT-SORT does.  Camera-motion compensation: ``update(..., warp=)`` applies the
+2 x 3 warp of the previous frame -> this one as BoT-SORT's ``multi_gmc`` does (means and covariances of all pooled and unconfirmed tracks, after the
+prediction step); boxmot's default estimator (ECC) is oracle/ecc.py, and ``camera_motion`` below is BoT-SORT's "sparseOptFlow" alternative with a
+fixed 8 x 6 grid instead of a corner detector (pyramidal LK of the key-point cadence, RANSAC over point pairs + least squares on the consensus
+set).  The association itself, as published:
 
   * constant-velocity Kalman filter on (cx, cy, w, h) with BoT-SORT's noise scaling (std_weight_position 1/20, std_weight_velocity 1/160);
   * detections split by confidence: high (> track_high_thresh 0.5) and low (track_low_thresh 0.1 < c < 0.5);

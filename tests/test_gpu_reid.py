@@ -1,5 +1,5 @@
 """-m gpu: the appearance branch of the tracker (the reference's BotSort runs with OSNet-x0.25 ReID, cm.py:66-72, 577).
-(1) eagle_reid_features (crop + resize + normalise + OSNet-x0.25 on the GPU) against oracle/reid.py (torch-CPU restatement, parity unpinned);
+(1) eagle_reid_features (crop + resize + normalise + OSNet-x0.25 on the GPU) against oracle/reid.py (numpy restatement, parity unpinned);
 (2) eagle_track_frames_reid against oracle/tracker.py with the same embeddings: ids through a crossing of two players whose boxes coincide —
     appearance is the only thing that tells them apart — and unchanged behaviour without embeddings."""
 import numpy as np

@@ -32,9 +32,11 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
-static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 13; }
-static int conv_ad_rows(const ConvConfig& c) { return (c.variant == 8 || c.variant == 10) ? 4 : c.variant == 13 ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
-static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10; }
+static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 15; }
+static bool conv_ad_s2t(const ConvConfig& c) { return c.variant == 14 || c.variant == 15; }      // TRUE stride 2 on a column-plane halo (14: BN 192; 15: BN 96, K split over wave pairs)
+static bool conv_ad_s2d(const ConvConfig& c) { return c.variant == 10 || c.variant == 11; }      // stride 2 over the space-to-depth image (variants 14 / 15: true stride 2, the stride-1 weight image)
+static int conv_ad_rows(const ConvConfig& c) { return (c.variant == 8 || c.variant == 10 || conv_ad_s2t(c)) ? 4 : c.variant == 13 ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
+static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10 || c.variant == 14; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
@@ -51,8 +53,9 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
         return conv_ws(c) ? operands + strips + 16 : std::max(operands + 16, strips);
     }
     if (precision == EAGLE_PREC_F32S && conv_ad(c)) {      // same halo ring as the fp16 kernel (16 logical channels = the 96-byte record), strips of 16 pixels x 48 channels x 4 bytes
-        const int slabs = (((conv_ad_rows(c) + 2) * 34 * 96 + 1023) / 1024 + 3) / 4 * 4;
-        return (size_t)(c.variant == 13 ? 1 : 2) * slabs * 1024 + 4 * 16 * 208;       // variant 13: one halo buffer
+        const int hpix = conv_ad_s2t(c) ? (2 * conv_ad_rows(c) + 1) * 66 : (conv_ad_rows(c) + 2) * 34;      // variants 14 / 15: 9 rows x (33 even + 33 odd columns)
+        const int slabs = ((hpix * 96 + 1023) / 1024 + 3) / 4 * 4;
+        return (size_t)((c.variant == 13 || conv_ad_s2t(c)) ? 1 : 2) * slabs * 1024 + 4 * 16 * 208;       // variants 13 - 15: one halo buffer
     }
     if (precision == EAGLE_PREC_F32S) {                    // hi and lo fragment blocks per K-step; 2 * kc fp16 values per staged pixel; 4-byte outputs
         const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 2 * 4 * bn * 16 + (size_t)hh * hw * f16_ps(2 * c.kc);
@@ -82,7 +85,11 @@ static const Inst g_ad_inst[] = {
     // the same Cout with four pixel groups (16 x 32 tile) and a single halo buffer (variant 13)
     {EAGLE_PREC_F32S, 3, 1, 16, 3, 13, nullptr},
     // split family, stride 2 over the space-to-depth image (variants 10 / 11)
-    {EAGLE_PREC_F32S, 3, 2, 16, 12, 10, nullptr}, {EAGLE_PREC_F32S, 3, 2, 16, 6, 11, nullptr}};
+    {EAGLE_PREC_F32S, 3, 2, 16, 12, 10, nullptr}, {EAGLE_PREC_F32S, 3, 2, 16, 6, 11, nullptr},
+    // split family, TRUE stride 2 on an even / odd column-plane halo, the stride-1 weight image (variant 14: BN = 192, tile 4 x 32, one halo buffer)
+    {EAGLE_PREC_F32S, 3, 2, 16, 12, 14, nullptr},
+    // the same with BN = 96: two Cout groups, the K dimension split over wave pairs (variant 15)
+    {EAGLE_PREC_F32S, 3, 2, 16, 6, 15, nullptr}};
 
 const Inst* conv_inst_part(int part, int* n)
 {
@@ -155,11 +162,20 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
             ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = atoi(getenv("EAGLE_CONV_KQ")) == 13 ? 13 : 12;
             return q;
         }
+        // 3x3 stride 2 with Cin = 48 k, Cout = 96 k (HRNet's transition / fuse down-sampling chains): the TRUE stride-2 A-direct forms.  Same box, all
+        // instances per layer (tools/convbench/split_tune, B = 50, best other form -> this one): 96->192 145 -> 108 us, 48->192 80 -> 62, 192->384
+        // 139 -> 102, 96->384 76 -> 55, 48->384 45 -> 33 (variant 14); 48->96 203 -> 175, 96->96 88 -> 70 (variant 15).  EAGLE_CONV_S2T=0: off.
+        static const bool s2t_on = !(getenv("EAGLE_CONV_S2T") && atoi(getenv("EAGLE_CONV_S2T")) == 0);
+        if (sad_on && s2t_on && plain_epilogue && ks == 3 && stride == 2 && cin_pad % 48 == 0 && cout_pad % 96 == 0) {
+            ConvConfig q = c; q.kc = 16;
+            if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 14; } else { q.nt = 6; q.variant = 15; }
+            return q;
+        }
         if (tuned_on)
             for (const Tuned& t : g_tuned_split)
                 if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
                     ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = t.variant;
-                    if (conv_ad(q) && !(sad_on && plain_epilogue && (stride == 2 ? cin_pad % 16 == 0 : cin_pad % 48 == 0))) continue;       // the A-direct kernels: ReLU / none after at most two residual adds, three chunks per loop body
+                    if (conv_ad(q) && !(sad_on && plain_epilogue && (conv_ad_s2d(q) ? cin_pad % 16 == 0 : cin_pad % 48 == 0))) continue;       // the A-direct kernels: ReLU / none after at most two residual adds, three chunks per loop body
                     if (find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
                 }
         if (sad_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 96 == 0) {      // A-direct, split form (three 16-channel chunks per loop body)
@@ -236,7 +252,7 @@ size_t conv_weight_elems(int precision, const ConvConfig& c)
     if (precision == EAGLE_PREC_F16 && conv_ad(c) && c.stride == 2) return (size_t)(c.cout_pad / (c.nt * 16)) * (4 * c.cin / 32) * 16 * (c.nt * 16) * 8;
     const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc;
     if (precision == EAGLE_PREC_F16) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 4 * bn * 8;
-    if (precision == EAGLE_PREC_F32S && conv_ad(c) && c.stride == 2) return (size_t)nblk * (4 * c.cin / 16) * 6 * 4 * bn * 8;      // 6 K-steps per 16-channel chunk of the space-to-depth image
+    if (precision == EAGLE_PREC_F32S && conv_ad_s2d(c)) return (size_t)nblk * (4 * c.cin / 16) * 6 * 4 * bn * 8;      // 6 K-steps per 16-channel chunk of the space-to-depth image
     if (precision == EAGLE_PREC_F32S && conv_ad(c)) return (size_t)nblk * (c.cin / 16) * 14 * 4 * bn * 8;   // 14 K-steps per 16-channel chunk
     if (precision == EAGLE_PREC_F32S) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 2 * 4 * bn * 8;      // fp16 elements: a hi and a lo block per K-step
     return (size_t)nblk * nch * c.ks * c.ks * (c.kc / 4) * 4 * bn;
@@ -259,7 +275,7 @@ void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int c
         const float scale = std::ldexp(1.0f, sw);
         if (descale) *descale = std::ldexp(1.0f, -(sw + 4));
         _Float16* d = (_Float16*)dst;
-        if (conv_ad(c) && c.stride == 2) {
+        if (conv_ad_s2d(c)) {
             // stride 2: [Cout block][s2d chunk][K-step 0..5][q][BN][8].  s2d chunk -> (phase (ry, rx), 16 real channels); K-steps 0..3 = the taps' (tyy, txx)
             // of the 2x2 kernel over the space-to-depth image, lane groups (hi g0, hi g1, hi g0, hi g1); K-steps 4, 5 = the tap' pairs (0|1), (2|3), lane
             // groups (lo g0, lo g1 | lo g0, lo g1).  tap' row 0 is the s2d row above: only its odd phase contributes (ky = 0); row 1: ky = 1 (even phase), 2 (odd).
@@ -406,9 +422,9 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
         const bool split = precision == EAGLE_PREC_F32S;
-        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((c.variant == 10 || c.variant == 11) ? 2 : 1) || (split && c.stride == 1 && c.cin % 48) || (split && c.stride == 2 && c.cin % 16))
+        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((conv_ad_s2d(c) || conv_ad_s2t(c)) ? 2 : 1) || (split && !conv_ad_s2d(c) && c.cin % 48) || (split && conv_ad_s2d(c) && c.cin % 16) || (conv_ad_s2t(c) && !split))
             fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32 (16 in the split family, stride 1 only), 2-byte / split output, pre_act none, post_act in {none, ReLU}");
-        if (c.stride == 2) a.nchunks = split ? 4 * c.cin / 16 : 4 * c.cin / 32;      // chunks of the space-to-depth image
+        if (conv_ad_s2d(c)) a.nchunks = split ? 4 * c.cin / 16 : 4 * c.cin / 32;      // chunks of the space-to-depth image
         const int thh = conv_ad_rows(c);
         a.tiles_x = (a.Wo + 31) / 32; a.tiles_y = (a.Ho + thh - 1) / thh;
         a.gy = c.cout_pad / (c.nt * 16);
@@ -416,7 +432,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)

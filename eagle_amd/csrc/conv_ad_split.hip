@@ -32,6 +32,14 @@ ConvKernel conv_ad_split_kernel_s2(bool wide, int n_res)      // stride 2 over t
     return fn[wide ? 1 : 0][n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
 }
 
+ConvKernel conv_ad_split_kernel_s2t(bool wide, int n_res)      // TRUE stride 2: column-plane halo, stride-1 weight image, one halo buffer (variants 14 / 15)
+{
+    static const ConvKernel fn[2][3] = {
+        {conv_split_ad_kernel<2, 1, 0, 2, true, false, true>, conv_split_ad_kernel<2, 1, 1, 2, true, false, true>, conv_split_ad_kernel<2, 1, 2, 2, true, false, true>},
+        {conv_split_ad_kernel<4, 1, 0, 1, true, false, true>, conv_split_ad_kernel<4, 1, 1, 1, true, false, true>, conv_split_ad_kernel<4, 1, 2, 1, true, false, true>}};
+    return fn[wide ? 1 : 0][n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
+}
+
 ConvKernel conv_ad_split_kernel(bool wide, int n_res)
 {
     static const ConvKernel fn[2][3] = {

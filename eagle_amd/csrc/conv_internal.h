@@ -39,6 +39,7 @@ ConvKernel conv_ad_kernel_s2(bool wide, int n_res);
 ConvKernel conv_ad_split_kernel(bool wide, int n_res);      // EAGLE_PREC_F32S form (conv_ad_split.inc), stride 1
 ConvKernel conv_ad_split_kernel48(int n_res);               // the same for Cout = 48 (K split over wave pairs; variant 12)
 ConvKernel conv_ad_split_kernel_s2(bool wide, int n_res);    // stride 2 (variants 10 / 11 of the split family)
+ConvKernel conv_ad_split_kernel_s2t(bool wide, int n_res);   // TRUE stride 2 on a column-plane halo, single halo buffer: BN = 192 (variant 14) / BN = 96 with the K split (variant 15)
 ConvKernel conv_ad_split_kernel48sb(int n_res);             // Cout = 48, 16 x 32 tile, single halo buffer (variant 13)
 
 }  // namespace eagle

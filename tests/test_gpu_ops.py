@@ -223,6 +223,31 @@ def test_conv_split_a_direct_stride2(cin, cout, shape, res, post, monkeypatch):
     assert err < F32S_TOL, f"split stride-2 A-direct conv error {err}"
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 192), (48, 192), (192, 384), (48, 384), (144, 192), (48, 96), (96, 96), (48, 288)])
+@pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (2, 68, 120), (1, 1, 1), (2, 130, 129), (1, 9, 200)])
+@pytest.mark.parametrize("res,post", [(True, 1), (False, 0), (2, 1)])
+def test_conv_split_a_direct_true_stride2(cin, cout, shape, res, post, monkeypatch):
+    """Variants 14 / 15: the stride-1 A-direct kernel over an even / odd column-plane halo (true stride 2, no space-to-depth padding; Cin = 48 k;
+    Cout = 192 k: four Cout groups; Cout = 96 k: two Cout groups with the K dimension split over wave pairs), forced through EAGLE_CONV_FORCE: odd and even input sizes, partial tiles in both directions, several tiles per row (the 65-column
+    halo), a 1 x 1 input, 0 - 2 residual operands."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    if shape[1] * shape[2] > 4000 and (cin > 96 or not res):
+        pytest.skip("large map: one representative case")
+    monkeypatch.setenv("EAGLE_CONV_FORCE", "16,12,14" if cout % 192 == 0 else "16,6,15")
+    n, h, w = shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    x = _rand((n, h, w, cin), 81)
+    wt = _rand((3, 3, cin, cout), 82, (2.0 / (cin * 9)) ** 0.5)
+    b = _rand((cout,), 83, 0.1)
+    r1 = _rand((n, ho, wo, cout), 84) if res else None
+    r2 = _rand((n, ho, wo, cout), 85) if res == 2 else None
+    ref = P.conv2d(x, wt, b, stride=2, pre=0, r1=r1, r2=r2, post=post)
+    got = lib.op_conv2d(x, wt, b, 2, 0, r1, r2, post, lib.PREC_F32S)
+    err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < F32S_TOL, f"split true-stride-2 A-direct conv error {err}"
+
+
 def test_conv_split_saturates_instead_of_overflowing():
     """An output beyond the split format's range (|v| > 4094) clips to +-65504 / 16 instead of becoming inf (and NaN one layer later)."""
     from eagle_amd import lib

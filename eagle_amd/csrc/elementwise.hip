@@ -179,7 +179,7 @@ struct FuseArgs { TView base, y; TView z[3]; float sh[3], sw[3]; int n_up; int r
 // registers and loads a row only when the bilinear footprint moves on: 2 loads per operand per NEW low-resolution row instead of 4 per output row
 // (x8 up-sampling: 0.5 per output row instead of 4).  Same arithmetic per output, in the same order: results are bit-identical to the one-row form.
 // The row decomposition is scalar, one integer division per thread remains, and the scale factors arrive as arguments.
-constexpr int FUSE_ROWS = 8;
+constexpr int FUSE_ROWS = 8;       // (16: 116.3 / 112.9 -> 119.8 / 115.6 us, same box)
 template <typename T, int NUP>
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
 {

@@ -140,3 +140,25 @@ def test_bad_arguments():
     with pytest.raises(lib.EagleError):
         h.clip_motion_ecc(0, 1)                             # no open clip session
     h.close()
+
+
+def test_reference_tracker_configuration_is_repeatable_over_a_long_clip():
+    """The reference's whole BotSort configuration — association + OSNet appearance + ECC camera motion — over a 120-frame clip in the 25-fps
+    cadence (HRNet every 8th frame, optical flow in between): two independent models give identical dictionaries (no run-to-run noise in any of
+    the three stages), ids are positive integers that persist (far fewer ids than detections), every frame is present."""
+    from eagle_amd.coordinate_model import CoordinateModel
+    frames = np.stack([synth.frame(0, t) for t in range(120)])
+    outs = []
+    for _ in range(2):
+        cm = CoordinateModel(batch=8, tracker=True, reid=True, camera_motion="ecc", detector_conf=0.2)
+        outs.append(cm.get_coordinates(frames, fps=25, num_homography=1, num_keypoint_detection=3))
+        cm.handle.close()
+    assert sorted(outs[0]) == list(range(120))
+    assert outs[0] == outs[1]
+    ids, n_obj = set(), 0
+    for i in outs[0]:
+        for cname in ("Player", "Goalkeeper"):
+            for oid in outs[0][i]["Coordinates"].get(cname, {}):
+                assert isinstance(oid, int) and oid >= 0
+                ids.add(oid); n_obj += 1
+    assert n_obj > 0 and len(ids) * 4 <= n_obj          # tracks persist: on average an id is seen on at least four frames

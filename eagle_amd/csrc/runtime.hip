@@ -1496,13 +1496,13 @@ int eagle_clip_motion_ecc(EagleHandle* h, int first, int count, int carry, doubl
     const int dh = (int)lrint(c.cv.h * SCALE), dw = (int)lrint(c.cv.w * SCALE), n = c.cv.n;
     if (dh < 4 || dw < 4) fail(EAGLE_E_INVALID, "eagle_clip_motion_ecc: frame too small for the 0.15-scale alignment");
     hipStream_t sm = h->s_main;
-    if (!c.ecc_small && n > 0) {
-        HIP_CHECK(hipMalloc(&c.ecc_small, (size_t)n * dh * dw));
-        HIP_CHECK(hipMalloc(&c.ecc_pairs, sizeof(int2) * n));
-        HIP_CHECK(hipMalloc(&c.ecc_out, sizeof(eagle::EccResult) * n));
-        c.ecc_h = dh; c.ecc_w = dw;
+    if (c.ecc_h == 0 && n > 0) {                          // first call of the session (ecc_h is set last: a failed allocation is retried, not half-used)
+        if (!c.ecc_small) HIP_CHECK(hipMalloc(&c.ecc_small, (size_t)n * dh * dw));
+        if (!c.ecc_pairs) HIP_CHECK(hipMalloc(&c.ecc_pairs, sizeof(int2) * n));
+        if (!c.ecc_out) HIP_CHECK(hipMalloc(&c.ecc_out, sizeof(eagle::EccResult) * n));
         HIP_CHECK(hipStreamWaitEvent(sm, c.ev_gray, 0));
         eagle::ecc_small_launch(c.g[0], c.ecc_small, n, c.cv.h, c.cv.w, dh, dw, sm);
+        c.ecc_h = dh; c.ecc_w = dw;
     }
     const bool use_carry = carry && h->ecc_has_prev && h->ecc_prev_h == dh && h->ecc_prev_w == dw;
     // every adjacent pair at once; pairs behind a failed alignment (boxmot keeps the old template) are re-run one by one below

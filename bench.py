@@ -289,7 +289,7 @@ def main():
 
     def int_field_diffs(rec, ref):
         """Integer-field differences of two record arrays of the same frames (per-field counts over all frames)."""
-        c = dict(frames=len(ref), hm_idx=0, n_kp=0, kp_pixels=0, n_det=0, det_cls=0, det_int_box=0, det_pitch_int=0, H_valid=0, dets_compared=0)
+        c = dict(frames=len(ref), hm_idx=0, n_kp=0, kp_pixels=0, n_det=0, det_cls=0, det_int_box=0, det_pitch_int=0, H_valid=0, dets_compared=0, det_unmatched=0)
         for g, o in zip(rec, ref):
             c["hm_idx"] += int((g["hm_idx"] != o["hm_idx"]).sum())
             c["H_valid"] += int(g["H_valid"] != o["H_valid"])
@@ -306,6 +306,10 @@ def main():
             c["det_cls"] += int((g["det"]["cls"][:k] != o["det"]["cls"][:k]).sum())
             c["det_int_box"] += int(np.any([g["det"][f][:k] != o["det"][f][:k] for f in ("bx1", "by1", "bx2", "by2")], axis=0).sum())
             c["det_pitch_int"] += int(((g["det"]["pitch_x"][:k] != o["det"]["pitch_x"][:k]) | (g["det"]["pitch_y"][:k] != o["det"]["pitch_y"][:k])).sum())
+            # order-independent view: detections of the reference whose (class, integer box) does not occur anywhere in this frame on the other side —
+            # what is left of det_int_box / det_cls once near-tie confidences that swap two rows of the NMS order are taken out
+            have = {(int(d["cls"]), int(d["bx1"]), int(d["by1"]), int(d["bx2"]), int(d["by2"])) for d in g["det"][:k]}
+            c["det_unmatched"] += sum((int(d["cls"]), int(d["bx1"]), int(d["by1"]), int(d["bx2"]), int(d["by2"])) not in have for d in o["det"][:k])
         return c
 
     exact = fast = parity = cfg3 = None

@@ -135,11 +135,36 @@ def test_coordinate_model_with_ecc_motion_equals_the_tracker_fed_with_oracle_war
     assert np.abs(w1[1:] - IDENT).max() > 1e-3             # the estimator did something on these frames
 
 
-def test_bad_arguments():
+def test_bad_arguments_and_degenerate_ranges():
+    from eagle_amd.coordinate_model import CoordinateModel
     h = _handle()
     with pytest.raises(lib.EagleError):
         h.clip_motion_ecc(0, 1)                             # no open clip session
-    h.close()
+    f = [synth.frame(0, t) for t in (1, 2, 3)]
+    d = h.upload(np.stack(f))
+    try:
+        h.clip_open(d, 3)
+        w0, ok0 = h.clip_motion_ecc(0, 0, return_ok=True)  # empty range
+        assert w0.shape == (0, 6) and ok0.shape == (0,)
+        with pytest.raises(lib.EagleError):
+            h.clip_motion_ecc(2, 2)                         # beyond the clip
+        w_all = h.clip_motion_ecc(0, 3)
+        w_last = h.clip_motion_ecc(2, 1)                    # a range that starts inside the clip is aligned to its predecessor
+        assert np.array_equal(w_last[0], w_all[2])
+        h.clip_close()
+        h.clip_open(d, 1)                                   # a one-frame clip: identity, and the frame becomes the carried template
+        h.track_open()
+        assert np.array_equal(h.clip_motion_ecc(0, 1, carry=True)[0], IDENT)
+        h.clip_close()
+        h.clip_open(d, 3)
+        w_c = h.clip_motion_ecc(0, 3, carry=True)
+        h.clip_close()
+        assert np.abs(w_c[0] - IDENT).max() < 1e-6           # frame 0 against the carried copy of itself: the identity (rho = 1 at once)
+        assert np.array_equal(w_c[1:], w_all[1:])
+    finally:
+        h.free(d); h.close()
+    with pytest.raises(ValueError):
+        CoordinateModel(batch=1, tracker=True, camera_motion="dense")
 
 
 def test_reference_tracker_configuration_is_repeatable_over_a_long_clip():

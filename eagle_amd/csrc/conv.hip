@@ -30,7 +30,7 @@ namespace eagle {
 static int f16_ps(int kc) { const int g = kc / 8; return kc * 2 + ((g % 2 == 0) ? 16 : 0); }
 static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
-static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : (c.variant == 4 ? 1 : 4); }
+static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : c.variant == 4 ? 1 : c.variant == 18 ? 6 : 4; }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
 static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 15; }
 static bool conv_ad_s2t(const ConvConfig& c) { return c.variant == 14 || c.variant == 15; }      // TRUE stride 2 on a column-plane halo (14: BN 192; 15: BN 96, K split over wave pairs)
@@ -150,8 +150,10 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         // whose LDS footprint lets two workgroups share a CU.  EAGLE_CONV_FORCE applies as below.
         if (const char* f = getenv("EAGLE_CONV_FORCE")) {
             ConvConfig q = c;
-            if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 && find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024)
-                return q;
+            if (sscanf(f, "%d,%d,%d", &q.kc, &q.nt, &q.variant) == 3 && cin_pad % q.kc == 0 && cout_pad % (16 * q.nt) == 0 && find_inst(precision, q)) {
+                if (q.variant == 18) q.wx = 3;              // the 8 x 48 tile
+                if (lds_bytes(precision, q) <= 160 * 1024) return q;
+            }
         }
         static const bool sad_on = !(getenv("EAGLE_CONV_AD") && atoi(getenv("EAGLE_CONV_AD")) == 0);
         static const bool tuned_on = !(getenv("EAGLE_CONV_TUNED") && atoi(getenv("EAGLE_CONV_TUNED")) == 0);

@@ -248,6 +248,26 @@ def test_conv_split_a_direct_true_stride2(cin, cout, shape, res, post, monkeypat
     assert err < F32S_TOL, f"split true-stride-2 A-direct conv error {err}"
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 45), (1, 16, 16), (2, 135, 240), (2, 9, 100), (1, 8, 48), (1, 1, 1)])
+@pytest.mark.parametrize("res,post", [(True, 1), (False, 0), (2, 1)])
+def test_conv_split_8x48_tile(shape, res, post, monkeypatch):
+    """Variant 18 of the generic split kernel: six 16-pixel sub-tiles per wave, 8 x 48 output tiles (HRNet's 240-pixel-wide 48-channel branch: 240 = 5 x 48),
+    forced through EAGLE_CONV_FORCE: exact and partial tiles in both directions, 0 - 2 residual operands."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    monkeypatch.setenv("EAGLE_CONV_FORCE", "16,3,18")
+    n, h, w = shape
+    x = _rand((n, h, w, 48), 101)
+    wt = _rand((3, 3, 48, 48), 102, (2.0 / (48 * 9)) ** 0.5)
+    b = _rand((48,), 103, 0.1)
+    r1 = _rand((n, h, w, 48), 104) if res else None
+    r2 = _rand((n, h, w, 48), 105) if res == 2 else None
+    ref = P.conv2d(x, wt, b, stride=1, pre=0, r1=r1, r2=r2, post=post)
+    got = lib.op_conv2d(x, wt, b, 1, 0, r1, r2, post, lib.PREC_F32S)
+    err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < F32S_TOL, f"split 8x48-tile conv error {err}"
+
+
 def test_conv_split_saturates_instead_of_overflowing():
     """An output beyond the split format's range (|v| > 4094) clips to +-65504 / 16 instead of becoming inf (and NaN one layer later)."""
     from eagle_amd import lib

@@ -45,15 +45,16 @@ int main(int argc, char** argv)
     hipMemset(db, 0, 1 << 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     static const int kcs[] = {64, 48, 32, 24, 16, 8}, nts[] = {12, 6, 4, 3, 2, 1};
-    static const int variants[] = {0, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+    static const int variants[] = {0, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 18};
     const char* only = getenv("TUNE_ONLY");          // "variant" or "variant,kc,nt": restrict the sweep
     for (auto& sh : shapes) {
         std::tie(ks, s, cin, cout, h, w, n) = sh;
         const int ho = (h + 2 * (ks / 2) - ks) / s + 1, wo = (w + 2 * (ks / 2) - ks) / s + 1;
         for (int res = 0; res <= ((ks == 3 && s == 1 && cin == cout) ? 1 : 0); ++res)
-        for (int variant : variants) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 2; ++wx) {
+        for (int variant : variants) for (int kc : kcs) for (int nt : nts) for (int wx = 1; wx <= 3; ++wx) {
             if (cin % kc || cout % (16 * nt)) continue;
-            if (variant >= 8 && wx != 2) continue;
+            if (variant >= 8 && variant != 18 && wx != 2) continue;
+            if ((variant == 18) != (wx == 3)) continue;          // the 8 x 48 tile is the only user of wx = 3
             if (only) { int ov = -1, okc = -1, ont = -1; sscanf(only, "%d,%d,%d", &ov, &okc, &ont); if (ov != variant || (okc > 0 && okc != kc) || (ont > 0 && ont != nt)) continue; }
             ConvLaunch L;
             L.cfg.ks = ks; L.cfg.stride = s; L.cfg.kc = kc; L.cfg.nt = nt; L.cfg.wx = wx; L.cfg.cin = cin; L.cfg.cout_pad = cout; L.cfg.variant = variant;

@@ -20,6 +20,7 @@ static const Inst g_split0[] = {
     ALLS(3, 1, 16), ALLS(3, 1, 32), ALLSH(3, 1, 16), ALLSH(3, 1, 32),
     // 8 x 48 tiles (variant 18, wx = 3: six 16-pixel sub-tiles per wave) for 240-pixel-wide maps: 240 = 5 x 48, 135 = 17 x 8 - 1 -> 0.7 % of the tile area is
     // outside the image instead of 7.4 % with 8 x 32 tiles, and the weight slice is staged once per 384 instead of per 256 pixels
+    // (Cout = 64 with NT = 4 / 2 measured: the strips of six sub-tiles leave one workgroup per CU, 16 x 16 tiles stay ahead: 64->64 373-388 us)
     {EAGLE_PREC_F32S, 3, 1, 16, 3, 18, conv_f16_kernel<3, 1, 16, 3, false, 6, true>},
     // (measured and not kept: chunk-pipelined staging, variant 2 of the fp16 family — 48->48 276 vs 273 us, 96->96 227 vs 224 us)
 };

@@ -437,7 +437,10 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         const ConvKernel fn = (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
-        static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : 512;      // developer knob: resident workgroups (co-residency experiments)
+        // workgroups per launch: one per item (the hardware hands a queued workgroup to whichever CU frees a slot: dynamic balance) rather than 512
+        // resident ones walking static item ranges — same box, alternating: 774.4 / 774.5 -> 779.0 / 780.7 frames/s, 96->96 209.9 -> 204.4 us,
+        // 192->192 180.3 -> 177.2 (768 workgroups: 707 frames/s — 1.5 rounds of uneven ranges).  EAGLE_CONV_AD_SLOTS=512 restores the persistent form.
+        static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : (1 << 30);
         hipLaunchKernelGGL(fn, dim3(std::min(items, slots)), dim3(256), lds_bytes(precision, c), s, a);
         HIP_CHECK(hipGetLastError());
         return;

@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the per-frame path (detect + keypoints + homography) at 1280x720.
 
-One "step" = one pass of the hot path over one device batch of ``--batch`` synthetic frames that are already
-resident in HBM (C ABI: eagle_process_device_frames).  Default run = BASELINE.json configs[1]: a 1000-frame
-1280x720 synthetic clip, YOLOv8-n detector + HRNet-W48 keypoint model, one MI355X (20 steps x 50 frames).
-The K timed steps are issued as ONE library call over the K*batch-frame clip so that the library's two-deep pipeline
-(geometry + record copy of step i under the networks of step i+1) is part of what is measured.
-Multi-GPU (driver launches one rank per GPU through torch.distributed.run): frames shard by contiguous chunk,
-weights replicated, no data-path collective; ONE all-gather of the fixed-size records at the end (inside the timed
-region); value = total frames of all ranks / max-over-ranks time  ("scaling": "weak").
+One "step" = one pass of the hot path over one device batch of ``--batch`` synthetic frames.  Default run = BASELINE.json configs[1]: a
+1000-frame 1280x720 synthetic clip, YOLOv8-n detector + HRNet-W48 keypoint model, one MI355X (20 steps x 50 frames).  The K timed steps are
+issued as ONE library call over the K*batch-frame clip so that the library's two-deep pipeline (upload of step i+1 and geometry + record copy of
+step i-1 under the networks of step i) is part of what is measured.
 
-Default family = EAGLE_PREC_F32S ("f32s": fp32-grade results — records equal the fp32 oracle's, tests/test_gpu_pipeline.py::test_f32s_* —
-computed as three fp16 MFMAs per product over (hi, lo) binary16 tensors).  ``value`` = frames/s with the clip already resident in HBM (the
-measurement contract's definition).  The same line also carries ``pcie_inclusive`` (SURVEY §8d's definition: the frames start in HOST
-memory; pageable memory through the library's pinned ring, and pinned memory), ``fast_family`` (the fp16 family on the same clip),
-``exact_family`` (the bit-exact fp32 family on the same clip), ``parity_counters`` (integer-field differences of both faster families against
-the exact family's records on the distinct frames of the clip — GPU against GPU, the exact family being the one that equals the oracle bit
-for bit), ``cfg3`` (BASELINE configs[2]: 1920x1080, yolov8l@960, a 200-frame run of both families), ``roofline`` (MFMA, the convolution
-family) and ``roofline_hbm`` (the bandwidth-bound kernels against 8 TB/s, HIP events on their launch streams / algorithmic bytes).
+``value`` (SURVEY §8d's metric: H2D of the frame -> ... -> record on the host): the clip starts in PAGEABLE HOST memory (numpy) and goes through
+``eagle_process_frames`` — worker threads copy each batch into the library's pinned ring, the DMA runs on a copy stream under the previous batch's
+networks.  ``resident`` is the same path with the clip already in HBM (``eagle_process_device_frames``; the two differ by < 1 %), ``host_sources``
+adds the pinned-source rate.
 
-Prints ONE JSON line on rank 0.  The CPU oracle appears here only as the timed ``cpu_baseline`` leg.  At N = 1 torch is not imported
-before the GPU work (the library has its own streams and synchronises its calls itself)."""
+Default handle = ``eagle_default_config``: key-point network in EAGLE_PREC_F32S ("f32s": every tensor value a (hi, lo) binary16 pair, three fp16 MFMAs
+per product — fp32-grade: heat-map maxima / key-points / H equal the fp32 oracle's on every test frame, floats to a few 1e-6), detector in the EXACT
+fp32 family (boxes, confidences, classes, NMS order and detection-index ids bit-identical to the fp32 oracle: tests/test_gpu_pipeline.py::
+test_default_handle_dense_detector_is_exception_free_*).  ``parity_counters`` counts integer-field differences against the exact family's records on
+the distinct frames of the clip (GPU against GPU; the exact family is the one that equals the oracle bit for bit).  Also in the line:
+``fast_family`` (fp16), ``exact_family`` (fp32), ``split_detector`` (both networks in f32s: round 3's headline), ``cfg3`` (BASELINE configs[2]:
+1000 frames 1920x1080, yolov8l@960), ``roofline`` (MFMA, the convolution family of the key-point precision, with ``dominant_kernel``),
+``roofline_conv_layers``, ``roofline_hbm``, ``saturation`` (clipped f32s stores: 0 in a healthy run), ``cpu_baseline``.
+
+Multi-GPU (driver launches one rank per GPU through torch.distributed.run): frames shard by contiguous chunk, weights replicated, no data-path
+collective; ONE all-gather of the fixed-size records at the end (inside the timed region); value = total frames of all ranks / max-over-ranks time
+("scaling": "weak").  torch is imported only there, and BEFORE the HIP library is loaded (one ROCm runtime per process: eagle_amd/lib.py::
+require_torch_first); at N = 1 the process that touches the GPU never imports torch — the CPU baseline runs first, in a child process.
+
+Prints ONE JSON line on rank 0.  The CPU oracle appears here only as the timed ``cpu_baseline`` leg."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -75,6 +81,28 @@ def cpu_baseline(hs, ys, frames, n_frames, threads, budget_s=25.0, variant="n", 
                       f"numpy/C host logic), {threads} threads ({usable_cpus()} usable of {os.cpu_count()} logical CPUs), {dt:.1f} s"}
 
 
+def cpu_baseline_child(a):
+    """--cpu-baseline-only: the child process of the default run (torch lives here, never in the process that touches the GPU)."""
+    from eagle_amd import synth, weights
+    hs = weights.make_hrnet_state_dict(0)
+    ys = weights.make_yolo_state_dict(a.detector, 0)
+    frames = synth.clip(seed=0, n=min(a.distinct, a.batch), h=a.height, w=a.width)
+    print(json.dumps(cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())), variant=a.detector, imgsz=a.imgsz)), flush=True)
+    # (all 256 hardware threads of the GPU box were tried once: torch-CPU convolutions collapse to 0.004 frames/s, 247 s for one
+    #  frame, profiles/r02b_bench_default_1gpu.json, so the bounded sample stays at 16 threads and says so)
+
+
+def cpu_baseline_subprocess(a):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--detector", a.detector, "--imgsz", str(a.imgsz), "--height", str(a.height),
+           "--width", str(a.width), "--cpu-frames", str(a.cpu_frames), "--distinct", str(a.distinct), "--batch", str(a.batch)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        sys.stderr.write(r.stderr)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                                # reported, never silent
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"cpu baseline child failed: {e!r}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,36 +114,52 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--precision", default="f32s", choices=["f16", "f32", "f32s"],
-                    help="f32s (default): split-precision family, fp32-grade results (records equal the fp32 oracle's); f16: the fast family; f32: the bit-exact family")
+                    help="family of the key-point network. f32s (default): split precision, fp32-grade; f16: the fast family; f32: the bit-exact family")
+    ap.add_argument("--det-precision", default="default", choices=["default", "f16", "f32", "f32s"],
+                    help="family of the detector. default: the library's (exact fp32 next to f32s key-points, otherwise the key-point family)")
     ap.add_argument("--distinct", type=int, default=20, help="distinct synthetic frames generated (tiled to the clip)")
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU restatement and print its JSON object")
     ap.add_argument("--graph", action="store_true", help="replay the network phase as a hipGraph (no gain once a step is GPU-bound)")
-    ap.add_argument("--host-frames", action="store_true", help="(kept for compatibility: the PCIe-inclusive path is always timed at N = 1)")
     ap.add_argument("--all-layers", action="store_true", help="roofline_conv_layers lists every convolution layer shape instead of the ten heaviest")
-    ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / exact_family / roofline_hbm (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip resident / host_sources / families / cfg3 / roofline_hbm (profiling runs)")
     ap.add_argument("--exact-frames", type=int, default=1000, help="frames of the fp32 exact-family run (0: skip)")
     ap.add_argument("--fast-frames", type=int, default=1000, help="frames of the fp16 fast-family run (0: skip)")
-    ap.add_argument("--cfg3-frames", type=int, default=200, help="frames of the configs[2] run (1920x1080, yolov8l@960; 0: skip)")
+    ap.add_argument("--cfg3-frames", type=int, default=1000, help="frames of the configs[2] run (1920x1080, yolov8l@960; 0: skip)")
     ap.add_argument("--cadence", type=int, default=0, metavar="FPS", help="also time the reference's default cadence on the same clip: get_coordinates(frames, FPS, num_homography=1, "
                     "num_keypoint_detection=3) = HRNet every int(FPS/3)-th frame, optical-flow propagation in between (stateful; reported as reference_cadence, never as value)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --shared-gpu: dev test of the multi-rank path on one GPU)")
     ap.add_argument("--shared-gpu", action="store_true", help="every rank uses HIP device 0 (developer test only)")
+    ap.add_argument("--force-multirank-path", action="store_true",
+                    help="take the WORLD_SIZE > 1 code path at world 1 (process group, library RCCL bootstrap, gather inside the timed region, max over ranks): "
+                         "the one-GPU regression test of the process composition the driver runs at N = 8")
     a = ap.parse_args()
+    if a.cpu_baseline_only:
+        cpu_baseline_child(a)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    multi = world > 1 or a.force_multirank_path
+
+    cpu_base = None
+    if not multi and not a.no_cpu_baseline:                # rank 0 at N = 1 only (the measurement contract); before the GPU is touched, in a child
+        cpu_base = cpu_baseline_subprocess(a)
+        log(f"cpu_baseline: {cpu_base}")
 
     dist = torch = None
     dev_index = 0 if a.shared_gpu else local_rank
     tdev = "cuda" if a.backend == "nccl" else "cpu"
-    if world > 1:
-        import torch
+    if multi:
+        import torch                                       # BEFORE the HIP library is loaded: one ROCm runtime per process (lib.require_torch_first)
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                # --force-multirank-path without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         if a.backend == "nccl":
             torch.cuda.set_device(dev_index)
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -128,13 +172,15 @@ def main():
     B, K, W = a.batch, a.steps, a.warmup
     hs = weights.make_hrnet_state_dict(0)
     ys = weights.make_yolo_state_dict(a.detector, 0)
+    det_kw = {} if a.det_precision == "default" else {"det_precision": lib.PRECISIONS[a.det_precision] + 1}
     h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
-                   batch=B, precision=lib.PRECISIONS[a.precision],
-                   use_graph=1 if a.graph else 0)
+                   batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if a.graph else 0, **det_kw)
+    inv_prec = {v: k for k, v in lib.PRECISIONS.items()}
+    det_prec_name = inv_prec[h.cfg.det_precision - 1] if h.cfg.det_precision else a.precision
     weights.load_into(h, [hs, ys])
-    log(f"rank {rank}: handle ready (batch {B})")
+    log(f"rank {rank}: handle ready (batch {B}, key-points {a.precision}, detector {det_prec_name})")
     gather_used = a.gather
-    if world > 1 and a.gather == "rccl":
+    if multi and a.gather == "rccl":
         try:
             shard.init_rccl(h, rank, world)
         except Exception as e:                        # labelled, never silent: reported in the JSON line
@@ -145,15 +191,13 @@ def main():
         if int(flag.item()):
             gather_used = "dist"
 
-    # this rank's contiguous chunk of the (weak-scaled) clip: K*B frames per rank (distinct content per rank), resident in HBM
+    # this rank's contiguous chunk of the (weak-scaled) clip: K*B frames per rank (distinct content per rank), in pageable host memory
     n_local = K * B
     base = synth.clip(seed=rank, n=min(a.distinct, n_local), h=a.height, w=a.width)
-    clip = np.concatenate([base] * (-(-n_local // len(base))))[:n_local]
+    clip = np.ascontiguousarray(np.concatenate([base] * (-(-n_local // len(base))))[:n_local])
     frames = clip[:B]
-    d_clip = h.upload(clip)                           # inputs resident in HBM before the timed region
-    log(f"rank {rank}: {n_local} frames resident in HBM")
     out = np.zeros(n_local, lib.RESULT_DTYPE)
-    gathered = np.zeros(n_local * world, lib.RESULT_DTYPE) if world > 1 else None
+    gathered = np.zeros(n_local * world, lib.RESULT_DTYPE) if multi else None
     if gathered is not None:
         gathered.view(np.uint8)[::4096] = 0          # touch the pages before the timed region
 
@@ -162,33 +206,42 @@ def main():
             dist.barrier()
 
     if W > 0:
-        h.process_device(d_clip, min(W, K) * B, out[:min(W, K) * B])
+        h.process(clip[:min(W, K) * B], out[:min(W, K) * B])
     sync()
     t0 = time.perf_counter()
-    h.process_device(d_clip, n_local, out)            # K steps of B frames
-    if world > 1:
-        allrec = shard.gather_records(out, n_local * world, rank, world, handle=h, transport=gather_used, out=gathered)
+    h.process(clip, out)                              # K steps of B frames, from pageable host memory (eagle_process_frames)
+    if multi:
+        allrec = shard.gather_records(out, n_local * world, rank, world, handle=h, transport=gather_used, out=gathered, force=True)
     else:
         allrec = out
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_frames = n_local * world
     assert len(allrec) == total_frames
-    log(f"timed region {dt:.3f} s -> {total_frames / dt:.1f} frames/s")
+    if multi:
+        lo = rank * n_local
+        assert allrec[lo:lo + n_local].tobytes() == out.tobytes(), "the gathered records of this rank differ from its own"
+    tm = h.timings()
+    saturation = {"sat_events": int(tm.sat_events), "sat_frames": int(tm.sat_frames),
+                  "note": "f32s activation stores clipped at +-4094 during the timed call (EagleTimings; a non-zero count makes the call return EAGLE_E_RANGE)"}
+    log(f"timed region {dt:.3f} s -> {total_frames / dt:.1f} frames/s (host frames)")
 
-    extras = world == 1 and not a.no_extras
-    pcie = None
+    extras = not multi and not a.no_extras
+    d_clip = h.upload(clip)                           # the clip resident in HBM: resident rate, profiling, family runs
+    resident = hostsrc = None
     if extras:
-        # SURVEY §8d's metric: the clip starts in host memory.  (a) pageable numpy memory -> worker threads -> pinned ring -> DMA;
-        # (b) pinned memory (eagle_host_alloc: where a decoder would write its frames) -> DMA in place.
-        h.process(clip[:2 * B])
+        o2 = np.zeros(n_local, lib.RESULT_DTYPE)
+        h.process_device(d_clip, min(2 * B, n_local), o2[:min(2 * B, n_local)])
         t1 = time.perf_counter()
-        h.process(clip)
-        r_page = n_local / (time.perf_counter() - t1)
+        h.process_device(d_clip, n_local, o2)
+        r_res = n_local / (time.perf_counter() - t1)
+        assert o2.tobytes() == out.tobytes(), "resident-input records differ from host-input records"
+        resident = {"value": round(r_res, 2), "unit": "frames/s", "value_over_resident": round(total_frames / dt / r_res, 4),
+                    "note": "eagle_process_device_frames: the clip already in HBM when the timed region starts; records identical to the host-fed run's"}
         hp = h.host_frames(n_local)
         hp[:] = clip
         h.process(hp[:2 * B])
@@ -196,12 +249,11 @@ def main():
         h.process(hp)
         r_pin = n_local / (time.perf_counter() - t1)
         h.host_free(hp)
-        pcie = {"value": round(r_page, 2), "unit": "frames/s", "frac_of_resident": round(r_page / (total_frames / dt), 4),
-                "pinned_source": round(r_pin, 2), "pinned_frac_of_resident": round(r_pin / (total_frames / dt), 4),
-                "note": "eagle_process_frames: value = frames in pageable host memory (copied into the library's pinned ring by "
-                        f"{os.environ.get('EAGLE_COPY_THREADS', '8')} worker threads, then DMA on a copy stream under the networks of the previous batch); "
-                        "pinned_source = frames in eagle_host_alloc memory, DMA in place"}
-        log(f"PCIe-inclusive: {r_page:.1f} frames/s from pageable memory, {r_pin:.1f} from pinned memory")
+        hostsrc = {"pageable": round(total_frames / dt, 2), "pinned": round(r_pin, 2), "unit": "frames/s",
+                   "note": "eagle_process_frames: pageable = value (frames copied into the library's pinned ring by "
+                           f"{os.environ.get('EAGLE_COPY_THREADS', '8')} worker threads, then DMA on a copy stream under the networks of the previous batch); "
+                           "pinned = frames in eagle_host_alloc memory, DMA in place"}
+        log(f"resident {r_res:.1f} frames/s, pinned source {r_pin:.1f} frames/s")
 
     cadence = None
     if a.cadence > 0:
@@ -212,7 +264,7 @@ def main():
         t1 = time.perf_counter()
         clipmod.run_clip(h, d_clip, n_local, kint, hint, False, st)
         dtc = time.perf_counter() - t1
-        if world > 1:                                    # configs[4] shape: one clip per rank (the cadence is sequential within a clip), slowest rank counts
+        if multi:                                        # configs[4] shape: one clip per rank (the cadence is sequential within a clip), slowest rank counts
             tc = torch.tensor([dtc], device=tdev, dtype=torch.float64)
             dist.all_reduce(tc, op=dist.ReduceOp.MAX)
             dtc = float(tc.item())
@@ -250,28 +302,38 @@ def main():
         kt = hh.kernel_times()
         hh.set_profiling(0)
         return ms, flop, nc, kt, prof_steps
-    conv_ms, conv_flop, n_conv, ktimes, prof_steps = profile(h, d_clip, B)
-    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # bandwidth-bound kernels: algorithmic bytes (inputs once + outputs once, counted by the library per launch) / HIP-event time
+    _, _, _, ktimes, prof_steps = profile(h, d_clip, B)
+    # The handle may run its two networks in two families (default: detector in exact fp32).  `roofline` is the KEY-POINT network's family (98.6 % of
+    # the FLOP); the detector's launches (labels end in " d") are reported separately against their own family's peak (`detector_convs`).
+    conv_ms = conv_flop = 0.0; n_conv = 0; conv_bytes = 0.0
+    det_ms = det_flop = 0.0; n_det_conv = 0
     hbm_rows, conv_rows = [], []
-    conv_bytes = sum(nbytes for name, _, _, nbytes, _ in ktimes if name.startswith("conv "))
     for name, ms, launches, nbytes, flop in ktimes:
         if name.startswith("conv ") and ms > 0:
+            is_det = name.endswith(" d") and det_prec_name != a.precision
+            peak = PEAK[det_prec_name if is_det else a.precision]
             us = ms * 1e3 / launches
-            conv_rows.append({"layer": name[5:], "launches_per_step": launches // prof_steps, "avg_us": round(us, 2), "ms_per_step": round(ms / prof_steps, 3),
-                              "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "frac_mfma": round(flop / (ms * 1e-3) / 1e12 / PEAK[a.precision], 4),
+            if is_det:
+                det_ms += ms; det_flop += flop; n_det_conv += launches
+            else:
+                conv_ms += ms; conv_flop += flop; n_conv += launches; conv_bytes += nbytes
+            conv_rows.append({"layer": name[5:], "family": det_prec_name if is_det else a.precision, "launches_per_step": launches // prof_steps, "avg_us": round(us, 2),
+                              "ms_per_step": round(ms / prof_steps, 3),
+                              "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "frac_mfma": round(flop / (ms * 1e-3) / 1e12 / peak, 4),
                               "GBps_algorithmic": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_hbm_6p3TBps": round(nbytes / (ms * 1e-3) / 1e9 / 6300.0, 4)})
             continue
         if nbytes > 0 and ms > 0:
             gbps = nbytes / (ms * 1e-3) / 1e9
             hbm_rows.append({"kernel": name, "launches_per_step": launches // prof_steps, "bytes_algorithmic_per_step": round(nbytes / prof_steps),
                              "avg_us": round(ms * 1e3 / launches, 2), "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4)})
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    dom = max((r for r in conv_rows if r["family"] == a.precision), key=lambda r: r["ms_per_step"], default=None)
 
     def family_run(prec, nframes, Bf, d_frames, hw=(a.height, a.width), det=a.detector, imgsz=a.imgsz, sd=None, want_records=0, det_prec=None):
         """A second handle of another precision family on frames that are already resident: frames/s (K steps of Bf in one call), the
-        convolution family's HIP-event roofline, optionally the records of the first `want_records` frames."""
+        convolution family's HIP-event roofline, optionally the records of the first `want_records` frames.  det_prec None: detector in `prec`."""
         hf = lib.Handle(device=dev_index, frame_h=hw[0], frame_w=hw[1], det_variant=det, det_imgsz=imgsz, batch=Bf, precision=lib.PRECISIONS[prec],
-                        det_precision=0 if det_prec is None else lib.PRECISIONS[det_prec] + 1)
+                        det_precision=lib.PRECISIONS[det_prec or prec] + 1)
         weights.load_into(hf, sd or [hs, ys])
         nf = max(Bf, nframes // Bf * Bf)
         of = np.zeros(nf, lib.RESULT_DTYPE)
@@ -279,17 +341,19 @@ def main():
         t1 = time.perf_counter()
         hf.process_device(d_frames, nf, of)
         dtf = time.perf_counter() - t1
-        fms, fflop, fnc, _, fsteps = profile(hf, d_frames, Bf, 1)
+        mixed = det_prec is not None and det_prec != prec
+        r = {"dtype": prec if not mixed else f"{prec} key-points + {det_prec} detector", "value": round(nf / dtf, 2), "unit": "frames/s", "frames": nf, "frames_per_step": Bf}
+        if not mixed:
+            fms, fflop, fnc, _, fsteps = profile(hf, d_frames, Bf, 1)
+            ach = fflop / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
+            r["roofline"] = {"bound": "mfma", "kernel": CONV_KERNEL[prec], "achieved": round(ach, 2), "peak": round(PEAK[prec], 1), "unit": "TFLOP/s",
+                             "frac": round(ach / PEAK[prec], 4), "conv_ms_per_step": round(fms / fsteps, 3), "flop_per_frame": fflop / (fsteps * Bf)}
         hf.close()
-        ach = fflop / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
-        r = {"dtype": prec, "value": round(nf / dtf, 2), "unit": "frames/s", "frames": nf, "frames_per_step": Bf,
-             "roofline": {"bound": "mfma", "kernel": CONV_KERNEL[prec], "achieved": round(ach, 2), "peak": round(PEAK[prec], 1), "unit": "TFLOP/s",
-                          "frac": round(ach / PEAK[prec], 4), "conv_ms_per_step": round(fms / fsteps, 3), "flop_per_frame": fflop / (fsteps * Bf)}}
         return r, of[:want_records].copy()
 
     def int_field_diffs(rec, ref):
         """Integer-field differences of two record arrays of the same frames (per-field counts over all frames)."""
-        c = dict(frames=len(ref), hm_idx=0, n_kp=0, kp_pixels=0, n_det=0, det_cls=0, det_int_box=0, det_pitch_int=0, H_valid=0, dets_compared=0, det_unmatched=0)
+        c = dict(frames=len(ref), hm_idx=0, n_kp=0, kp_pixels=0, n_det=0, det_cls=0, det_int_box=0, det_pitch_int=0, det_id=0, H_valid=0, dets_compared=0, det_unmatched=0)
         for g, o in zip(rec, ref):
             c["hm_idx"] += int((g["hm_idx"] != o["hm_idx"]).sum())
             c["H_valid"] += int(g["H_valid"] != o["H_valid"])
@@ -304,6 +368,7 @@ def main():
             k = int(o["n_det"])
             c["dets_compared"] += k
             c["det_cls"] += int((g["det"]["cls"][:k] != o["det"]["cls"][:k]).sum())
+            c["det_id"] += int((g["det"]["id"][:k] != o["det"]["id"][:k]).sum())
             c["det_int_box"] += int(np.any([g["det"][f][:k] != o["det"][f][:k] for f in ("bx1", "by1", "bx2", "by2")], axis=0).sum())
             c["det_pitch_int"] += int(((g["det"]["pitch_x"][:k] != o["det"]["pitch_x"][:k]) | (g["det"]["pitch_y"][:k] != o["det"]["pitch_y"][:k])).sum())
             # order-independent view: detections of the reference whose (class, integer box) does not occur anywhere in this frame on the other side —
@@ -312,26 +377,28 @@ def main():
             c["det_unmatched"] += sum((int(d["cls"]), int(d["bx1"]), int(d["by1"]), int(d["bx2"]), int(d["by2"])) not in have for d in o["det"][:k])
         return c
 
-    exact = fast = parity = cfg3 = None
+    exact = fast = parity = cfg3 = splitdet = None
     nd = len(base)
-    if extras and a.exact_frames > 0 and a.precision != "f32":
+    head_name = a.precision if det_prec_name == a.precision else f"{a.precision}+{det_prec_name}_detector"
+    if extras and a.exact_frames > 0 and (a.precision, det_prec_name) != ("f32", "f32"):
         # the exact family (fp32 tensors, v_mfma_f32_16x16x4_f32 fmaf chains): the kernels whose records equal the oracle's bit for bit
         exact, rec_exact = family_run("f32", a.exact_frames, B, d_clip, want_records=nd)
         exact["note"] = "same path and clip with EAGLE_PREC_F32: records bit-identical to the CPU oracle (tests/test_gpu_pipeline.py::test_f32_path_identical_to_oracle)"
         log(f"exact family (fp32): {exact['value']} frames/s, conv {exact['roofline']['achieved']:.1f} TFLOP/s")
         parity = {"reference": "records of the exact (fp32, oracle-identical) family on the same frames", "frames": nd,
-                  a.precision: int_field_diffs(out[:nd], rec_exact)}
+                  "default": head_name, head_name: int_field_diffs(out[:nd], rec_exact)}
+    if extras and a.precision == "f32s" and det_prec_name != "f32s":
+        splitdet, rec_sd = family_run("f32s", n_local, B, d_clip, want_records=nd)
+        splitdet["note"] = "both networks in the split family (round 3's headline configuration): the detector's near-tie confidences may swap neighbouring ids (parity_counters.f32s)"
+        log(f"split family incl. detector: {splitdet['value']} frames/s")
+        if parity is not None:
+            parity["f32s"] = int_field_diffs(rec_sd, rec_exact)
     if extras and a.fast_frames > 0 and a.precision != "f16":
         fast, rec_fast = family_run("f16", a.fast_frames, B, d_clip, want_records=nd)
         fast["note"] = "fp16 tensors, one fp16 MFMA per product: integer outputs are NOT guaranteed equal to the fp32 path's (see parity_counters); reported for reference, never as value"
         log(f"fast family (fp16): {fast['value']} frames/s, conv {fast['roofline']['achieved']:.1f} TFLOP/s")
-        # the mixed handle (EagleConfig::det_precision): key-points in fp16, the detector (1.4 % of the FLOPs) in the split family
-        mixed, rec_mixed = family_run("f16", a.fast_frames, B, d_clip, want_records=nd, det_prec="f32s")
-        fast["with_f32s_detector"] = {"value": mixed["value"], "unit": "frames/s", "note": "fp16 HRNet + f32s YOLOv8: boxes / confidences / NMS order / ids at fp32 grade"}
-        log(f"fast family with the detector in f32s: {mixed['value']} frames/s")
         if parity is not None:
             parity["f16"] = int_field_diffs(rec_fast, rec_exact)
-            parity["f16_with_f32s_detector"] = int_field_diffs(rec_mixed, rec_exact)
     if parity is not None:
         log(f"parity counters vs the exact family: {json.dumps(parity)}")
     if extras and a.cfg3_frames > 0 and (a.height, a.width, a.detector) == (720, 1280, "n"):
@@ -342,11 +409,15 @@ def main():
         base3 = synth.clip(seed=0, n=10, h=1080, w=1920)
         clip3 = np.concatenate([base3] * (-(-n3 // len(base3))))[:n3]
         d3 = h.upload(clip3)
-        cfg3 = {"workload": f"{n3}-frame 1920x1080 synthetic clip, yolov8l@960 + HRNet-W48 keypoints + RANSAC homography", "frames_per_step": B3}
-        for pr in (a.precision, "f16") if a.precision != "f16" else ("f16",):
-            r3, _ = family_run(pr, n3, B3, d3, hw=(1080, 1920), det="l", imgsz=960, sd=[hs, yl])
-            cfg3[pr] = r3
-            log(f"cfg3 {pr}: {r3['value']} frames/s, conv {r3['roofline']['achieved']:.1f} TFLOP/s")
+        del clip3
+        cfg3 = {"workload": f"{n3}-frame 1920x1080 synthetic clip, yolov8l@960 + HRNet-W48 keypoints + RANSAC homography (resident input)", "frames_per_step": B3}
+        runs = [("f32s", None), ("f16", None)] if a.precision == "f32s" else [(a.precision, None)]
+        if a.precision == "f32s" and det_prec_name == "f32":
+            runs.insert(0, ("f32s", "f32"))              # the default configuration: 210 of the 544 GFLOP per frame in the exact family
+        for pr, dp in runs:
+            r3, _ = family_run(pr, n3, B3, d3, hw=(1080, 1920), det="l", imgsz=960, sd=[hs, yl], det_prec=dp)
+            cfg3["default" if dp else pr] = r3
+            log(f"cfg3 {r3['dtype']}: {r3['value']} frames/s")
         h.free(d3)
 
     traffic = traffic_src = None
@@ -358,27 +429,46 @@ def main():
             traffic_src = f"NOT measured in this run: read from profiles/{os.path.basename(tf)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of build {tj.get('build', '?')}; the library's streams run concurrently in those passes, so kernels of other streams that overlap a convolution are counted into it: an upper bound)"
     res = None
     if rank == 0:
+        dt_names = {"f16": "f16", "f32": "f32", "f32s": "f32 (split: hi/lo binary16 pairs, 3 x fp16 MFMA per product, fp32 accumulate)"}
         res = {
             "metric": f"frames/sec end-to-end (detect+keypoint+homography) @{a.width}x{a.height}",
             "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f16": "f16", "f32": "f32", "f32s": "f32 (split: hi/lo binary16 pairs, 3 x fp16 MFMA per product, fp32 accumulate)"}[a.precision], "data": f"synthetic ({len(base)} distinct generated frames per rank tiled to {n_local}; seeded synthetic weights)",
+            "dtype": dt_names[a.precision] + ("" if det_prec_name == a.precision else f"; detector (1.4 % of the FLOP): {dt_names[det_prec_name]}, exact v_mfma_f32_16x16x4_f32 chains"),
+            "data": f"synthetic ({len(base)} distinct generated frames per rank tiled to {n_local}; seeded synthetic weights)",
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
-                       "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}",
-                       "gather": "none" if world == 1 else gather_used, "hip_graph": bool(a.graph)},
-            "roofline": {"bound": "mfma", "kernel": f"{CONV_KERNEL[a.precision]} (all {n_conv // prof_steps} convolution launches of a step)",
+                       "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}", "input": "pageable host memory (eagle_process_frames)",
+                       "keypoint_precision": a.precision, "detector_precision": det_prec_name,
+                       "gather": "none" if not multi else gather_used, "hip_graph": bool(a.graph)},
+            "roofline": {"bound": "mfma", "kernel": f"{CONV_KERNEL[a.precision]} (the {n_conv // prof_steps} convolution launches per step of the key-point network's family)",
                          "achieved": round(achieved, 2), "peak": round(PEAK[a.precision], 1), "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[a.precision], 4),
                          "flop_per_frame": conv_flop / (prof_steps * B), "avg_launch_us": round(conv_ms * 1e3 / max(n_conv, 1), 2),
                          "conv_ms_per_step": round(conv_ms / prof_steps, 3),
                          "algorithmic_bytes_per_launch": round(conv_bytes / max(n_conv, 1)),
+                         "dominant_kernel": None if dom is None else {"name": f"conv_f16_kernel / conv_split_ad_kernel instance of layer '{dom['layer']}'" if a.precision == "f32s" else dom["layer"],
+                                                                      "layer": dom["layer"], "launches_per_step": dom["launches_per_step"], "avg_us": dom["avg_us"],
+                                                                      "frac": dom["frac_mfma"], "ms_per_step": dom["ms_per_step"]},
                          "traffic": traffic, "traffic_source": traffic_src},
-            "value_is": "frames/s with the clip resident in HBM before the timed region (records land on the host inside it); pcie_inclusive.value is the same path fed from host memory",
+            "value_is": "frames/s with the clip in PAGEABLE HOST memory when the timed region starts (SURVEY §8d: H2D -> networks -> geometry -> records on the host); "
+                        "resident.value is the same path with the clip already in HBM",
+            "saturation": saturation,
         }
+        if det_prec_name != a.precision and det_ms > 0:
+            res["detector_convs"] = {"family": det_prec_name, "launches_per_step": n_det_conv // prof_steps, "ms_per_step_serialised": round(det_ms / prof_steps, 3),
+                                     "achieved": round(det_flop / (det_ms * 1e-3) / 1e12, 2), "peak": PEAK[det_prec_name], "unit": "TFLOP/s",
+                                     "frac": round(det_flop / (det_ms * 1e-3) / 1e12 / PEAK[det_prec_name], 4), "flop_per_frame": det_flop / (prof_steps * B),
+                                     "note": "runs on its own stream beside the key-point network in the timed region; serialised here by the profiling mode"}
+        if resident is not None:
+            res["resident"] = resident
+        if hostsrc is not None:
+            res["host_sources"] = hostsrc
         if hbm_rows:
             res["roofline_hbm"] = hbm_rows
-        if conv_rows:      # the ten convolution layer shapes that take the most time, each against BOTH roofs (MFMA peak; 6.3 TB/s achievable HBM)
+        if conv_rows:      # the ten convolution layer shapes that take the most time, each against BOTH roofs (MFMA peak of its family; 6.3 TB/s achievable HBM)
             res["roofline_conv_layers"] = sorted(conv_rows, key=lambda r: -r["ms_per_step"])[:(len(conv_rows) if a.all_layers else 10)]
+        if splitdet is not None:
+            res["split_detector"] = splitdet
         if fast is not None:
             res["fast_family"] = fast
         if exact is not None:
@@ -389,14 +479,10 @@ def main():
             res["cfg3"] = cfg3
         if cadence is not None:
             res["reference_cadence"] = cadence
-        if pcie is not None:
-            res["pcie_inclusive"] = pcie
         if cmc is not None:
             res["camera_motion_ecc"] = cmc
-        if not a.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only (the measurement contract)
-            res["cpu_baseline"] = cpu_baseline(hs, ys, frames, a.cpu_frames, max(1, min(16, usable_cpus())), variant=a.detector, imgsz=a.imgsz)
-            # (all 256 hardware threads of the GPU box were tried once: torch-CPU convolutions collapse to 0.004 frames/s, 247 s for one
-            #  frame, profiles/r02b_bench_default_1gpu.json, so the bounded sample stays at 16 threads and says so)
+        if cpu_base is not None:
+            res["cpu_baseline"] = cpu_base
     h.free(d_clip)
     h.close()
     if dist is not None:

@@ -21,7 +21,7 @@ class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
                  detector="n", det_imgsz=640, batch=8, precision="f32s", device=0, hrnet_state_dict=None,
                  detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False, detector_precision=None,
-                 reid=False, reid_state_dict=None):
+                 reid=False, reid_state_dict=None, allow_saturation=False):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
         if camera_motion not in (False, True, None, "sparse", "ecc"):
@@ -30,12 +30,15 @@ class CoordinateModel:
         self.reid = bool(reid) and tracker      # appearance matching inside the tracker (the reference's BotSort has it on: cm.py:66-72)
         self._tracker_open = False           # the reference builds ONE BotSort in __init__ (cm.py:66-72): ids keep counting across get_coordinates calls
         self.batch = batch
+        # detector_precision=None: the library's default — with precision="f32s" the detector runs in the exact fp32 family (boxes, confidences,
+        # classes, NMS order and hence every detection-index id equal the fp32 reference arithmetic bit for bit), otherwise in `precision`
+        dp = {} if detector_precision is None else {"det_precision": lib.PRECISIONS[detector_precision] + 1}
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
                                  det_imgsz=det_imgsz, batch=batch,
                                  precision=lib.PRECISIONS[precision],
-                                 det_precision=0 if detector_precision is None else lib.PRECISIONS[detector_precision] + 1,
                                  keypoint_conf=keypoint_conf, detector_conf=detector_conf,
-                                 detector_floor=min(detector_conf, 0.15), use_graph=int(use_graph))
+                                 detector_floor=min(detector_conf, 0.15), use_graph=int(use_graph),
+                                 allow_saturation=int(allow_saturation), **dp)
         # the reference reads eagle/models/weights/*.pt|.pth (cm.py:55-59); none exist here -> seeded synthetic
         hs = hrnet_state_dict if hrnet_state_dict is not None else weights.make_hrnet_state_dict(seed)
         ys = detector_state_dict if detector_state_dict is not None else weights.make_yolo_state_dict(detector, seed)
@@ -54,6 +57,10 @@ class CoordinateModel:
                         verbose: bool = True, calibration: bool = False) -> dict:
         homography_interval = max(1, int(fps / max(1, num_homography)))
         keypoint_interval = max(1, int(fps / max(1, num_keypoint_detection)))
+        if self.tracker:
+            # before ANY motion estimate: eagle_track_open forgets the ECC estimator's carried template, so opening the tracker lazily after the
+            # clip's camera motion (as until round 3) threw away the template this clip had just stored and mis-aligned the next clip's frame 0
+            self._ensure_tracker_open()
         if calibration or keypoint_interval != 1:
             motion = [] if (self.tracker and self.camera_motion) else None
             recs = self.flow_records(frames, keypoint_interval, homography_interval, calibration, motion=motion)
@@ -89,6 +96,13 @@ class CoordinateModel:
         """Forget every track: the next clip starts with a fresh tracker (frame counter 0, ids from 1), which is what a new
         ``CoordinateModel`` gives in the reference."""
         self._tracker_open = False
+        if self.tracker:
+            self._ensure_tracker_open()      # at once: the reset also drops the camera-motion estimator's template (boxmot's ECC object dies with its tracker)
+
+    def _ensure_tracker_open(self):
+        if not self._tracker_open:
+            self.handle.track_open()
+            self._tracker_open = True
 
     def reid_inputs(self, recs, high=0.5):
         """boxmot extracts appearance features for the high-confidence detections (conf > track_high_thresh) from ``frame[y1:y2, x1:x2]`` of
@@ -112,9 +126,7 @@ class CoordinateModel:
         """One clip: track ids + smoothed boxes into the records (frame order), pitch coordinates re-projected on the GPU.  Like the
         reference's single BotSort instance (cm.py:66-72, 577) the tracker state lives as long as the model: ids keep increasing over
         successive clips and only the very first frame ever seen activates its tracks at once; ``reset_tracker()`` starts over."""
-        if not self._tracker_open:
-            self.handle.track_open()
-            self._tracker_open = True
+        self._ensure_tracker_open()
         if self.reid and frames is not None:
             crops, det, count = self.reid_inputs(recs)
             frames = np.ascontiguousarray(frames, np.uint8)

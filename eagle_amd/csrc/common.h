@@ -67,6 +67,8 @@ struct ConvLaunch {
     // (maximum, first index) per channel and writes it to (*am_slot)[(frame * tiles + tile) * cout_pad + channel] (K5 fused into the
     // producer: the fp32 logit tensor never goes to HBM).  The slot is read when the launch is enqueued.
     ArgmaxPart* const* am_slot = nullptr;
+    // EAGLE_PREC_F32S: where the step being enqueued counts saturated stores per frame (EagleHandle::cur_sat; read when the launch is enqueued)
+    unsigned* const* sat_slot = nullptr;
 };
 // output tiles per frame of a convolution with this configuration (the number of partials per channel the fused arg-max writes)
 int conv_tiles_per_frame(const ConvConfig& cfg, int ho, int wo);
@@ -91,7 +93,7 @@ LetterBox letterbox_geometry(int h, int w, int imgsz);
 void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det,
                        const LetterBox& lb, hipStream_t s, int which = 3);
 struct FuseUp { TView z; };
-void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s);
+void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s, unsigned* sat = nullptr);   // sat: as ConvArgs::sat
 void maxpool5_launch(const TView& x, const TView& y, hipStream_t s);
 void upsample2_launch(const TView& x, const TView& y, hipStream_t s);
 
@@ -150,7 +152,7 @@ void gray_pyramid_launch(const uint8_t* d_bgr, int n, int h, int w, uint8_t* g0,
 void lk_launch(const ClipView& cv, int src_frame, int dst_frame, ChainState* st, const MemList* mem, int kint, hipStream_t s);
 // ---- ECC camera motion (ecc.hip, K17) ---------------------------------------------------------------------------------------------
 struct EccResult { int ok, iters; double rho; float M[6]; };       // M: 2 x 3 warp in the 0.15-scale image's pixels (template -> image)
-void ecc_small_launch(const uint8_t* gray, uint8_t* small, int n, int h, int w, int dh, int dw, hipStream_t s);
+void ecc_small_launch(const uint8_t* gray, uint8_t* small, int n, int h, int w, int dh, int dw, double inv_scale /* 1 / fx */, hipStream_t s);
 // pairs[k] = (template frame or -1 = `carry`, image frame), indices into `small` ([n, h, w] u8)
 void ecc_launch(const uint8_t* small, const uint8_t* carry, const int2* pairs, int n_pairs, EccResult* out, int h, int w, int max_iter, double eps, hipStream_t s);
 // ---- team colours (teams.hip, K15) ----------------------------------------------------------------------------------------------

@@ -422,6 +422,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.nchunks = c.cin / c.kc;
     a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
+    a.sat = (L.sat_slot && precision == EAGLE_PREC_F32S) ? *L.sat_slot : nullptr;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
         const bool split = precision == EAGLE_PREC_F32S;
         if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((conv_ad_s2d(c) || conv_ad_s2t(c)) ? 2 : 1) || (split && !conv_ad_s2d(c) && c.cin % 48) || (split && conv_ad_s2d(c) && c.cin % 16) || (conv_ad_s2t(c) && !split))

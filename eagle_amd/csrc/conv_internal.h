@@ -26,6 +26,8 @@ struct ConvArgs {
     float descale;          // EAGLE_PREC_F32S: 2^-(weight scale + 4), undoes the power-of-two operand scaling of the accumulator
     const void* zeros;      // >= 16 zero bytes in global memory (source of out-of-image pixels for unconditional loads / LDS-DMA)
     void* trash;            // >= 4 KiB of scratch global memory (target of out-of-image results for unconditional stores)
+    unsigned* sat;          // EAGLE_PREC_F32S: per-frame saturation counters [N] (a lane that stores a value beyond the split format's range of
+                            // +-4094 adds one to its frame's word), or nullptr: not counted (operator-level calls)
 };
 
 typedef void (*ConvKernel)(ConvArgs);

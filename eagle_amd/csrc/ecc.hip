@@ -19,13 +19,14 @@
 
 namespace eagle {
 
-__global__ __launch_bounds__(256) void ecc_small_kernel(const uint8_t* __restrict__ gray, uint8_t* __restrict__ small, int n, int h, int w, int dh, int dw)
+__global__ __launch_bounds__(256) void ecc_small_kernel(const uint8_t* __restrict__ gray, uint8_t* __restrict__ small, int n, int h, int w, int dh, int dw, double inv_scale)
 {
     const size_t total = (size_t)n * dh * dw, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int x = (int)(i % dw), y = (int)((i / dw) % dh), f = (int)(i / ((size_t)dw * dh));
         const uint8_t* s = gray + (size_t)f * h * w;
-        const ResizeTap ax = resize_tap(x, dw, w), ay = resize_tap(y, dh, h);
+        // cv2.resize(dsize = (0, 0), fx, fy) maps with 1 / fx, not with ssize / dsize: the two differ whenever 0.15 * size is not an integer
+        const ResizeTap ax = resize_tap_scaled(x, inv_scale, w), ay = resize_tap_scaled(y, inv_scale, h);
         const uint8_t* r0 = s + (size_t)ay.s0 * w; const uint8_t* r1 = s + (size_t)ay.s1 * w;
         const int t0 = r0[ax.s0] * ax.a0 + r0[ax.s1] * ax.a1;
         const int t1 = r1[ax.s0] * ax.a0 + r1[ax.s1] * ax.a1;
@@ -262,12 +263,12 @@ __global__ __launch_bounds__(ECC_THREADS) void ecc_kernel(const uint8_t* __restr
     }
 }
 
-void ecc_small_launch(const uint8_t* gray, uint8_t* small, int n, int h, int w, int dh, int dw, hipStream_t s)
+void ecc_small_launch(const uint8_t* gray, uint8_t* small, int n, int h, int w, int dh, int dw, double inv_scale, hipStream_t s)
 {
     if (n <= 0) return;
     const size_t total = (size_t)n * dh * dw;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(ecc_small_kernel, dim3(blocks), dim3(256), 0, s, gray, small, n, h, w, dh, dw);
+    hipLaunchKernelGGL(ecc_small_kernel, dim3(blocks), dim3(256), 0, s, gray, small, n, h, w, dh, dw, inv_scale);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -171,7 +171,7 @@ template <> struct Vec<float> {
 // K4: y = relu(((base + up(z0)) + up(z1)) + up(z2)), bilinear align_corners=True
 //     (F.interpolate + sum + ReLU, eagle/models/keypoint_hrnet.py:290-309)
 // ------------------------------------------------------------------------------------------------------------
-struct FuseArgs { TView base, y; TView z[3]; float sh[3], sw[3]; int n_up; int relu; };     // sh / sw: (z.h - 1) / (H - 1), (z.w - 1) / (W - 1) (fp32 division, done once on the host)
+struct FuseArgs { TView base, y; TView z[3]; float sh[3], sw[3]; int n_up; int relu; unsigned* sat; };     // sh / sw: (z.h - 1) / (H - 1), (z.w - 1) / (W - 1) (fp32 division, done once on the host)
 
 // One workgroup = 256 (column, channel-group) items of FUSE_ROWS consecutive output rows of one frame.  The kernel is not bound by HBM but by what it
 // pulls through the texture path: 1 + 4 * NUP operand loads per 32-byte output (13 with three low-resolution operands), almost all of them L2 hits on
@@ -254,14 +254,20 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
 #pragma unroll
             for (int k = 0; k < VN; ++k) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : 0.f;
         acc.store(a.y.p, (size_t)pix * a.y.cs + a.y.off + g * VN);
+        if constexpr (__is_same(T, SplitT)) {              // (Vec<SplitT> holds 16 x the value: the format's range is |16 v| <= 65504)
+            float m = 0.0f;
+#pragma unroll
+            for (int k = 0; k < VN; ++k) m = __builtin_fmaxf(m, __builtin_fabsf(acc.v[k]));
+            if (a.sat != nullptr && m > 65504.0f) atomicAdd(a.sat + n, 1u);
+        }
     }
 }
 
 static int ew_blocks(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 256 * 16); }
 
-void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s)
+void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s, unsigned* sat)
 {
-    FuseArgs a; a.base = base; a.y = y; a.n_up = n_up; a.relu = relu;
+    FuseArgs a; a.base = base; a.y = y; a.n_up = n_up; a.relu = relu; a.sat = sat;
     for (int i = 0; i < n_up; ++i) {
         a.z[i] = ups[i].z;
         a.sh[i] = (y.h > 1) ? (float)(ups[i].z.h - 1) / (float)(y.h - 1) : 0.f;

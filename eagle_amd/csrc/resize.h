@@ -9,9 +9,9 @@ namespace eagle {
 
 struct ResizeTap { int s0, s1; int a0, a1; };
 
-__device__ __forceinline__ ResizeTap resize_tap(int d, int dsize, int ssize)
+// scale = source pixels per destination pixel: ssize / dsize for cv2.resize(dsize), 1 / fx for cv2.resize((0, 0), fx, fy)
+__device__ __forceinline__ ResizeTap resize_tap_scaled(int d, double scale, int ssize)
 {
-    const double scale = (double)ssize / (double)dsize;
     float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
@@ -23,6 +23,7 @@ __device__ __forceinline__ ResizeTap resize_tap(int d, int dsize, int ssize)
     r.a1 = (int)(short)lrintf(f * 2048.f);
     return r;
 }
+__device__ __forceinline__ ResizeTap resize_tap(int d, int dsize, int ssize) { return resize_tap_scaled(d, (double)ssize / (double)dsize, ssize); }
 
 // resized RGB u8 pixel (dy, dx) of an (sh, sw) -> (dh, dw) resize; src is BGR with `rs` bytes per row
 __device__ __forceinline__ void resize_px_strided(const uint8_t* src, size_t rs, int sh, int sw, int dh, int dw, int dy, int dx, int rgb[3])

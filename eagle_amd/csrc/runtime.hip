@@ -157,6 +157,8 @@ struct EagleHandle {
         ArgmaxPart* parts = nullptr;
         EagleFrameResult* d_out = nullptr;
         EagleFrameResult* h_out = nullptr;   // pinned
+        unsigned* d_sat = nullptr;           // [batch] saturated stores per frame (EAGLE_PREC_F32S; ConvArgs::sat).  Lies SAT_PAD bytes in front of d_out
+        unsigned* h_sat = nullptr;           // (and of h_out): one memset and one device-to-host copy serve both
         uint8_t* d_frames = nullptr;         // staging copy of the batch (stable pointer for the captured graph)
         uint8_t* h_frames = nullptr;         // pinned ring slot for caller frames that live in pageable memory (allocated on first use)
         bool copy_pending = false;           // ev_copy has been recorded for this slot
@@ -174,6 +176,10 @@ struct EagleHandle {
     LetterBox lb;
     int hm_chunks = 64;                      // heat-map partials per channel and frame (fused: output tiles of the head convolution)
     ArgmaxPart* cur_parts = nullptr;         // where the head convolution of the step being enqueued writes its partials (fused K5)
+    unsigned* cur_sat = nullptr;             // where the f32s kernels of the step being enqueued count saturated stores per frame
+    unsigned* clip_sat = nullptr;            // the same for the passes of a clip session (read by eagle_clip_fetch), pinned host copy behind it
+    unsigned* clip_sat_h = nullptr;
+    long long sat_events = 0; int sat_frames = 0;      // of the last eagle_process_* / eagle_clip_fetch call
     bool fused_argmax = false;
     DetScratch ds;
     DetLevel levels[3];
@@ -206,6 +212,8 @@ struct EagleHandle {
         uint8_t* ecc_small = nullptr;      // K17: [n, ecc_h, ecc_w] 0.15-scale gray images (built on the first eagle_clip_motion_ecc call)
         int ecc_h = 0, ecc_w = 0;
         int2* ecc_pairs = nullptr; eagle::EccResult* ecc_out = nullptr;   // device, n entries
+        int ecc_next = -1, ecc_tmpl = -2;  // eagle_clip_motion_ecc called range after range: the frame the last call stopped in front of, and the template it left
+                                           // (a clip frame, or -1 = the carried template); a failed alignment keeps the OLD template across calls too
     } clip;
     // boxmot's ECC object lives as long as the tracker: the last template survives the clip (carried by eagle_clip_motion_ecc, reset by eagle_track_open)
     uint8_t* ecc_prev = nullptr; int ecc_prev_h = 0, ecc_prev_w = 0; bool ecc_has_prev = false;
@@ -224,6 +232,7 @@ struct Builder {
     int prec;
     double bn_eps;
     int N;
+    const char* label_suffix = "";          // appended to the convolution labels of this network (" d": the detector, so that profiles can tell the networks apart)
     int cur_stream = 0;
     void set_stream(int k) { cur_stream = k; net->pool = k; }
     void fork_join(Op::Kind kind, int nbranch) { Op op; op.kind = kind; op.nbranch = nbranch; op.tag = kind == Op::FORK ? "fork" : "join"; net->ops.push_back(op); }
@@ -298,11 +307,12 @@ struct Builder {
         if (r2) L.r2 = *r2;
         L.pre_act = pre; L.post_act = post; L.out_f32 = out_f32 ? 1 : 0;
         L.am_slot = am_slot;
+        if (prec == EAGLE_PREC_F32S && !out_f32 && !am_slot) L.sat_slot = &H->cur_sat;
         if (am_slot) { H->hm_chunks = conv_tiles_per_frame(L.cfg, ho, wo); H->fused_argmax = true; }
         L.flop = 2.0 * N * ho * wo * (double)cout * cin * ks * ks;
         const int pr = prec;
         char label[64];
-        snprintf(label, sizeof(label), "conv %dx%d/%d %d->%d @%dx%d", ks, ks, stride, cin, cout, ho, wo);
+        snprintf(label, sizeof(label), "conv %dx%d/%d %d->%d @%dx%d v%d%s", ks, ks, stride, cin, cout, ho, wo, L.cfg.variant, label_suffix);      // v: kernel form (conv.hip)
         net->names.emplace_back(new std::string(label));
         Op op; op.kind = Op::CONV; op.flop = L.flop; op.tag = net->names.back()->c_str(); op.stream = cur_stream;
         {   // algorithmic HBM bytes of the launch: input once, output once, each residual once, weights once
@@ -381,7 +391,8 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
             if (nu) {
                 TView o = B.act(y.h, y.w, y.c);
                 const TView base = y; FuseUp u0 = ups[0], u1 = ups[1], u2 = ups[2]; const int n_up = nu;
-                B.other([base, u0, u1, u2, n_up, o](hipStream_t s) { FuseUp u[3] = {u0, u1, u2}; fuse_sum_launch(base, u, n_up, 1, o, s); }, "fuse_sum",
+                EagleHandle* const Hh = B.H;
+                B.other([base, u0, u1, u2, n_up, o, Hh](hipStream_t s) { FuseUp u[3] = {u0, u1, u2}; fuse_sum_launch(base, u, n_up, 1, o, s, Hh->cur_sat); }, "fuse_sum",
                         Builder::vbytes(base) + Builder::vbytes(o) + (nu > 0 ? Builder::vbytes(ups[0].z) : 0) + (nu > 1 ? Builder::vbytes(ups[1].z) : 0) + (nu > 2 ? Builder::vbytes(ups[2].z) : 0));
                 for (int k = 0; k < nu; ++k) B.release(ups[k].z);
                 if (i != 0) B.release(y);
@@ -707,6 +718,8 @@ static void timed(EagleHandle* h, const char* name, double bytes, hipStream_t st
     h->spans.push_back(sp);
 }
 
+static size_t sat_pad_bytes(int B) { return ((size_t)B * sizeof(unsigned) + 255) & ~(size_t)255; }
+
 static void run_net(EagleHandle* h, Net* net, hipStream_t s, size_t& ev_i)
 {
     const bool multi = h->multi_stream && !h->prof;
@@ -747,7 +760,8 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     const int B = c.batch;
     EagleHandle::StepBuf& sb = h->sb[p];
     size_t ev_i = 0;
-    HIP_CHECK(hipMemsetAsync(sb.d_out, 0, sizeof(EagleFrameResult) * B, h->s_main));
+    HIP_CHECK(hipMemsetAsync(sb.d_sat, 0, sat_pad_bytes(B) + sizeof(EagleFrameResult) * B, h->s_main));      // saturation words + records
+    h->cur_sat = sb.d_sat;
     const double esz = h->prec == EAGLE_PREC_F16 ? 2 : 4;
     if (!(g_dbg_skip & 16))
         timed(h, "preprocess", (double)n_active * ((double)c.frame_h * c.frame_w * 3 + (540.0 * 960 + (double)h->lb.out_h * h->lb.out_w) * h->kp_in.c * esz), h->s_main,
@@ -806,7 +820,7 @@ static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_activ
         HIP_CHECK(hipStreamWaitEvent(sp, sb.ev_compute, 0));
     }
     if (!(g_dbg_skip & 8)) timed(h, "post (geometry)", 0, sp, [&] { post_launch(sb.parts, c.batch, h->pp, sb.d_out, sp); });
-    HIP_CHECK(hipMemcpyAsync(sb.h_out, sb.d_out, sizeof(EagleFrameResult) * n_active, hipMemcpyDeviceToHost, sp));
+    HIP_CHECK(hipMemcpyAsync(sb.h_sat, sb.d_sat, sat_pad_bytes(c.batch) + sizeof(EagleFrameResult) * n_active, hipMemcpyDeviceToHost, sp));
     HIP_CHECK(hipEventRecord(sb.ev_done, sp));
 }
 
@@ -814,6 +828,8 @@ static void collect_step(EagleHandle* h, int p, int n_active, EagleFrameResult* 
 {
     HIP_CHECK(hipEventSynchronize(h->sb[p].ev_done));
     memcpy(out, h->sb[p].h_out, sizeof(EagleFrameResult) * n_active);
+    for (int i = 0; i < n_active; ++i)                      // f32s: frames in which an activation left the split format's range (|v| > 4094) are flagged
+        if (h->sb[p].h_sat[i]) { out[i].pad[1] = 1; h->sat_events += h->sb[p].h_sat[i]; ++h->sat_frames; }
     h->timings.n_launches += h->n_launch;
     h->timings.n_conv_launches += h->n_conv;
     h->timings.conv_flop += h->conv_flop_step;
@@ -845,6 +861,7 @@ static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage sta
 {
     const int B = h->cfg.batch;
     memset(&h->timings, 0, sizeof(h->timings));
+    h->sat_events = 0; h->sat_frames = 0;
     if (n == 0) return;
     HIP_CHECK(hipEventRecord(h->ev_t0, h->s_main));
     int prev_n = 0, prev_i = 0, k = 0;
@@ -864,6 +881,17 @@ static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage sta
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
     h->timings.total_ms = ms;
+    h->timings.sat_events = (int32_t)std::min<long long>(h->sat_events, 0x7fffffff);
+    h->timings.sat_frames = h->sat_frames;
+}
+
+// EAGLE_PREC_F32S stores clip at +-4094 instead of overflowing; a call in which that happened must not look like a success
+static void check_saturation(EagleHandle* h, const char* what)
+{
+    if (h->sat_events > 0 && !h->cfg.allow_saturation)
+        fail(EAGLE_E_RANGE, "%s: %lld activation stores in %d frame(s) left the range of the f32s tensor format (|v| > 4094) and were clipped; the records are "
+             "written (EagleFrameResult.pad[1] marks the frames) but are not fp32-grade.  Use EAGLE_PREC_F32 for these weights, or set EagleConfig.allow_saturation",
+             what, h->sat_events, h->sat_frames);
 }
 
 // ---- clip session (optical-flow cadence) ----------------------------------------------------------------------------------
@@ -928,6 +956,7 @@ static void clip_open(EagleHandle* h, const uint8_t* d_bgr, int n)
     for (hipEvent_t* e : {&c.ev_gray, &c.ev_det, &c.ev_kp, &c.ev_loop}) HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     HIP_CHECK(hipMemsetAsync(c.mem, 0xFF, sizeof(MemList) * nn, h->s_main));                  // n = -1 everywhere
     HIP_CHECK(hipMemsetAsync(c.recs, 0, sizeof(EagleFrameResult) * nn, h->s_main));
+    HIP_CHECK(hipMemsetAsync(h->clip_sat, 0, sat_pad_bytes(cf.batch), h->s_main));
     HIP_CHECK(hipMemcpyAsync(c.st, c.h_zero, sizeof(ChainState), hipMemcpyHostToDevice, h->s_main));
     if (n > 0) gray_pyramid_launch(d_bgr, n, c.cv.h, c.cv.w, c.g[0], c.g[1], c.g[2], h->s_main);
     HIP_CHECK(hipEventRecord(c.ev_gray, h->s_main));
@@ -947,6 +976,7 @@ static void clip_detect_objects(EagleHandle* h, int first, int count)
     size_t ev_i = 0;
     EagleHandle::StepBuf& sb = h->sb[0];
     const bool prof = h->prof; h->prof = false;
+    h->cur_sat = h->clip_sat;
     // The passes of later chunks run under the sequential loop of earlier frames (three streams).  Round 1 had to serialise them
     // behind the loop because K12 was not reproducible next to the convolution kernels; the cause was the packed-fp32 code hipcc's
     // SLP vectoriser generated for K12 (Makefile), not the overlap.
@@ -973,6 +1003,7 @@ static void clip_detect_keypoints(EagleHandle* h, int first, int stride, int cou
     size_t ev_i = 0;
     EagleHandle::StepBuf& sb = h->sb[0];
     const bool prof = h->prof; h->prof = false;
+    h->cur_sat = h->clip_sat;
     for (int k0 = 0; k0 < count; k0 += B) {
         const int na = std::min(B, count - k0);
         const uint8_t* src;
@@ -1004,6 +1035,7 @@ static void finalize(EagleHandle* h)
     // inputs (written by the preprocess kernel)
     Builder Bh{h, h->hr.get(), h->prec, 1e-5, B};
     Builder By{h, h->yo.get(), h->det_prec, 1e-3, B};
+    By.label_suffix = " d";
     h->kp_in = Bh.act(540, 960, cin_pad);
     h->det_in = By.act(h->lb.out_h, h->lb.out_w, det_cin_pad);
     h->logits = build_hrnet(Bh, h->kp_in);
@@ -1018,12 +1050,17 @@ static void finalize(EagleHandle* h)
     for (auto& sb : h->sb) {
         sb.d_frames = (uint8_t*)m->get((size_t)B * c.frame_h * c.frame_w * 3);
         sb.parts = (ArgmaxPart*)m->get(sizeof(ArgmaxPart) * (size_t)B * h->hm_chunks * 64);
-        sb.d_out = (EagleFrameResult*)m->get(sizeof(EagleFrameResult) * (size_t)B);
-        HIP_CHECK(hipHostMalloc((void**)&sb.h_out, sizeof(EagleFrameResult) * (size_t)B, hipHostMallocDefault));
+        const size_t sat_pad = sat_pad_bytes(B);
+        sb.d_sat = (unsigned*)m->get(sat_pad + sizeof(EagleFrameResult) * (size_t)B);
+        sb.d_out = (EagleFrameResult*)((char*)sb.d_sat + sat_pad);
+        HIP_CHECK(hipHostMalloc((void**)&sb.h_sat, sat_pad + sizeof(EagleFrameResult) * (size_t)B, hipHostMallocDefault));
+        sb.h_out = (EagleFrameResult*)((char*)sb.h_sat + sat_pad);
         HIP_CHECK(hipEventCreateWithFlags(&sb.ev_compute, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&sb.ev_done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&sb.ev_copy, hipEventDisableTiming));
     }
+    h->clip_sat = (unsigned*)m->get(sat_pad_bytes(B));
+    HIP_CHECK(hipHostMalloc((void**)&h->clip_sat_h, sat_pad_bytes(B), hipHostMallocDefault));
     int A = 0;
     for (int l = 0; l < 3; ++l) A += h->levels[l].gh * h->levels[l].gw;
     h->ds.A = A;
@@ -1076,6 +1113,9 @@ int eagle_default_config(EagleConfig* cfg)
     cfg->keypoint_conf = 0.3; cfg->detector_conf = 0.35; cfg->ransac_thresh = 5.0;
     cfg->detector_floor = 0.15f; cfg->nms_iou = 0.7f;
     cfg->ransac_max_iters = 2000; cfg->lm_iters = 10; cfg->use_graph = 0;
+    // the detector (1.4 % of the FLOP with yolov8n) in the exact fp32 family: boxes, confidences, classes, the NMS order and therefore every
+    // detection-index id (cm.py:598-627) equal the fp32 oracle's bit for bit; the key-point network stays in the split family
+    cfg->det_precision = EAGLE_PREC_F32 + 1;
     return EAGLE_OK;
 }
 
@@ -1119,7 +1159,7 @@ void eagle_destroy(EagleHandle* h)
     (void)hipDeviceSynchronize();
     for (auto& sb : h->sb) {
         if (sb.gexec) (void)hipGraphExecDestroy(sb.gexec);
-        if (sb.h_out) (void)hipHostFree(sb.h_out);
+        if (sb.h_sat) (void)hipHostFree(sb.h_sat);       // (h_out lies inside it)
         if (sb.h_frames) (void)hipHostFree(sb.h_frames);
         if (sb.ev_compute) (void)hipEventDestroy(sb.ev_compute);
         if (sb.ev_done) (void)hipEventDestroy(sb.ev_done);
@@ -1131,6 +1171,7 @@ void eagle_destroy(EagleHandle* h)
     if (h->ecc_prev) (void)hipFree(h->ecc_prev);
     if (h->reid_crops_h) (void)hipHostFree(h->reid_crops_h);
     if (h->reid_feats_h) (void)hipHostFree(h->reid_feats_h);
+    if (h->clip_sat_h) (void)hipHostFree(h->clip_sat_h);
     if (h->s_main) (void)hipStreamDestroy(h->s_main);
     if (h->s_det) (void)hipStreamDestroy(h->s_det);
     if (h->s_post) (void)hipStreamDestroy(h->s_post);
@@ -1187,6 +1228,7 @@ int eagle_process_device_frames(EagleHandle* h, const void* d_bgr, int n, EagleF
         HIP_CHECK(hipMemcpyAsync(h->sb[p].d_frames, src, fsz * na, hipMemcpyDeviceToDevice, h->s_main));
         return h->sb[p].d_frames;
     });
+    check_saturation(h, "eagle_process_device_frames");
     API_END(h)
 }
 
@@ -1248,6 +1290,7 @@ int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t fram
         }
         return sb.d_frames;
     });
+    check_saturation(h, "eagle_process_frames");
     API_END(h)
 }
 
@@ -1293,9 +1336,11 @@ int eagle_reid_features(EagleHandle* h, const void* d_bgr, int n_frames, const E
     if (!h) return EAGLE_E_INVALID;
     API_BEGIN
     if (!h->finalized || !h->reid) fail(EAGLE_E_STATE, "no appearance network: load the reid.* tensors (OSNet-x0.25, torchreid names) before eagle_finalize_weights");
-    if (!d_bgr || n_frames < 0 || n_crops < 0 || (n_crops > 0 && (!crops || !feats))) fail(EAGLE_E_INVALID, "bad argument");
+    if (n_frames < 0 || n_crops < 0 || (n_crops > 0 && (!d_bgr || !crops || !feats))) fail(EAGLE_E_INVALID, "bad argument");
+    if (n_crops == 0) return EAGLE_OK;
     HIP_CHECK(hipSetDevice(h->cfg.device));
-    const bool prof = h->prof; h->prof = false;
+    struct ProfOff { EagleHandle* h; bool was; ~ProfOff() { h->prof = was; } } prof_guard{h, h->prof};      // restored on every exit path
+    h->prof = false;
     for (int i0 = 0; i0 < n_crops; i0 += eagle::REID_NB) {
         const int nb = std::min(eagle::REID_NB, n_crops - i0);
         for (int k = 0; k < eagle::REID_NB; ++k) {
@@ -1311,7 +1356,6 @@ int eagle_reid_features(EagleHandle* h, const void* d_bgr, int n_frames, const E
         HIP_CHECK(hipStreamSynchronize(h->s_main));
         memcpy(feats + (size_t)i0 * EAGLE_REID_DIM, h->reid_feats_h, sizeof(float) * EAGLE_REID_DIM * (size_t)nb);
     }
-    h->prof = prof;
     API_END(h)
 }
 
@@ -1336,6 +1380,18 @@ int eagle_track_frames_reid(EagleHandle* h, EagleFrameResult* recs, int n, const
     if (!recs || n < 0 || (feats && (!feat_det || !feat_count))) fail(EAGLE_E_INVALID, "bad argument");
     if (!h->tracker) fail(EAGLE_E_STATE, "eagle_track_open has not been called");
     if (n == 0) return EAGLE_OK;
+    if (feats)                                               // the caller's index arrays are untrusted: validate before anything is dereferenced
+        for (int i = 0; i < n; ++i) {
+            if (feat_count[i] < 0 || feat_count[i] > EAGLE_MAX_DET) fail(EAGLE_E_INVALID, "eagle_track_frames_reid: feat_count[%d] = %d", i, feat_count[i]);
+            if (recs[i].n_det < 0 || recs[i].n_det > EAGLE_MAX_DET) fail(EAGLE_E_INVALID, "eagle_track_frames_reid: record %d has n_det = %d", i, recs[i].n_det);
+        }
+    if (feats) {
+        size_t o = 0;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < feat_count[i]; ++k, ++o)
+                if (feat_det[o] < 0 || feat_det[o] >= recs[i].n_det)
+                    fail(EAGLE_E_INVALID, "eagle_track_frames_reid: feat_det[%zu] = %d is not a detection of record %d (n_det %d)", o, feat_det[o], i, recs[i].n_det);
+    }
     std::vector<double> Hs((size_t)n * 9, 0.0);
     std::vector<uint8_t> flags((size_t)n, 0);
     bool any = false;
@@ -1501,7 +1557,7 @@ int eagle_clip_motion_ecc(EagleHandle* h, int first, int count, int carry, doubl
         if (!c.ecc_pairs) HIP_CHECK(hipMalloc(&c.ecc_pairs, sizeof(int2) * n));
         if (!c.ecc_out) HIP_CHECK(hipMalloc(&c.ecc_out, sizeof(eagle::EccResult) * n));
         HIP_CHECK(hipStreamWaitEvent(sm, c.ev_gray, 0));
-        eagle::ecc_small_launch(c.g[0], c.ecc_small, n, c.cv.h, c.cv.w, dh, dw, sm);
+        eagle::ecc_small_launch(c.g[0], c.ecc_small, n, c.cv.h, c.cv.w, dh, dw, 1.0 / SCALE, sm);
         c.ecc_h = dh; c.ecc_w = dw;
     }
     const bool use_carry = carry && h->ecc_has_prev && h->ecc_prev_h == dh && h->ecc_prev_w == dw;
@@ -1521,6 +1577,7 @@ int eagle_clip_motion_ecc(EagleHandle* h, int first, int count, int carry, doubl
     }
     constexpr int NONE = -2;
     int prev = first > 0 ? first - 1 : (use_carry ? -1 : NONE);
+    if (first > 0 && c.ecc_next == first && c.ecc_tmpl != NONE && (c.ecc_tmpl >= 0 || use_carry)) prev = c.ecc_tmpl;   // the previous range ended behind a failed alignment
     for (int i = 0; i < count; ++i) {
         const int f = first + i;
         double* W = warps + (size_t)i * 6;
@@ -1541,6 +1598,7 @@ int eagle_clip_motion_ecc(EagleHandle* h, int first, int count, int carry, doubl
         W[2] = (double)(float)((double)r.M[2] / SCALE); W[5] = (double)(float)((double)r.M[5] / SCALE);   // warp_matrix[i, 2] /= self.scale
         prev = f;
     }
+    if (count > 0) { c.ecc_next = first + count; c.ecc_tmpl = prev; }
     if (carry && prev != NONE && prev != -1) {
         if (!h->ecc_prev || h->ecc_prev_h != dh || h->ecc_prev_w != dw) {
             if (h->ecc_prev) HIP_CHECK(hipFree(h->ecc_prev));
@@ -1593,6 +1651,12 @@ int eagle_clip_fetch(EagleHandle* h, EagleFrameResult* out)
     HIP_CHECK(hipSetDevice(h->cfg.device));
     eagle::clip_sync(h);
     if (h->clip.cv.n > 0) HIP_CHECK(hipMemcpy(out, h->clip.recs, sizeof(EagleFrameResult) * (size_t)h->clip.cv.n, hipMemcpyDeviceToHost));
+    // saturated f32s stores of the session's detector / key-point passes (counted per slot of the device batch, not per clip frame)
+    HIP_CHECK(hipMemcpy(h->clip_sat_h, h->clip_sat, eagle::sat_pad_bytes(h->cfg.batch), hipMemcpyDeviceToHost));
+    h->sat_events = 0; h->sat_frames = 0;
+    for (int i = 0; i < h->cfg.batch; ++i) if (h->clip_sat_h[i]) { h->sat_events += h->clip_sat_h[i]; ++h->sat_frames; }
+    h->timings.sat_events = (int32_t)std::min<long long>(h->sat_events, 0x7fffffff); h->timings.sat_frames = h->sat_frames;
+    eagle::check_saturation(h, "eagle_clip_fetch");
     API_END(h)
 }
 
@@ -1680,12 +1744,21 @@ typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t)
 typedef int (*fn_destroy)(void*);
 typedef const char* (*fn_errstr)(int);
 
+// A process must hold ONE copy of the ROCm runtime stack.  PyTorch-ROCm wheels bundle their own (torch/lib/libamdhip64.so, libhsa-runtime64.so,
+// librccl.so — SONAMEs libamdhip64.so.7 / librccl.so.1, the same as /opt/rocm's), so in a process that has imported torch the RCCL to use is the
+// one that is already mapped: RTLD_NOLOAD by SONAME finds it (round 3 opened "librccl.so.1" RTLD_GLOBAL from the search path, which next to an
+// already-imported torch could map a second RCCL against a second HIP runtime — DESIGN.md §8).  Only a torch-free process loads /opt/rocm's copy,
+// and never RTLD_GLOBAL: nothing else resolves symbols through it.
 static void* rccl_lib()
 {
     static void* lib = nullptr;
     if (!lib) {
+        for (const char* n : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (lib) return lib;
+        }
         for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
         }
     }

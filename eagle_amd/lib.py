@@ -20,18 +20,25 @@ class EagleError(RuntimeError):
     pass
 
 
+class EagleRangeError(EagleError):
+    """EAGLE_E_RANGE: the split-precision family clipped an activation at +-4094 (include/eagle.h).  The records were written and are attached as
+    ``.records`` (``pad[1]`` marks the frames); they are not fp32-grade."""
+    records = None
+
+
 class EagleConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("frame_h", C.c_int32), ("frame_w", C.c_int32), ("det_variant", C.c_int32),
                 ("det_imgsz", C.c_int32), ("batch", C.c_int32), ("precision", C.c_int32),
                 ("keypoint_conf", C.c_double), ("detector_conf", C.c_double), ("ransac_thresh", C.c_double),
                 ("detector_floor", C.c_float), ("nms_iou", C.c_float),
                 ("ransac_max_iters", C.c_int32), ("lm_iters", C.c_int32), ("use_graph", C.c_int32), ("det_precision", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("allow_saturation", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class EagleTimings(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("conv_ms", C.c_float), ("n_launches", C.c_int32),
-                ("n_conv_launches", C.c_int32), ("conv_flop", C.c_double), ("reserved", C.c_int32 * 8)]
+                ("n_conv_launches", C.c_int32), ("conv_flop", C.c_double), ("sat_events", C.c_int32), ("sat_frames", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class EagleTrackParams(C.Structure):
@@ -57,6 +64,19 @@ RESULT_DTYPE = np.dtype([("n_det", "<i4"), ("n_kp", "<i4"), ("n_candidates", "<i
                          ("kp", KP_DTYPE, MAX_KP), ("det", DET_DTYPE, MAX_DET)], align=True)
 
 _lib = None
+_gpu_touched = False      # a handle has been created in this process: the library's HIP runtime is initialised
+
+
+def require_torch_first():
+    """One process must hold ONE ROCm runtime.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 / librccl (SONAMEs identical
+    to /opt/rocm's): when torch is imported BEFORE this library is loaded, the dynamic loader binds libeagle_hip.so and the dlopen'ed RCCL to
+    torch's copies by SONAME — one runtime.  The other order maps /opt/rocm's runtime first and torch's second copy next to it (torch asks for
+    "libamdhip64.so", which matches no SONAME): two HSA runtimes in one process, which is what aborted at interpreter exit in round 3
+    (DESIGN.md §8).  Called by every code path of this package that imports torch after a handle may exist."""
+    import sys
+    if "torch" not in sys.modules and _gpu_touched:
+        raise EagleError("torch must be imported before eagle_amd.lib creates its first handle in a process that uses both "
+                         "(two ROCm runtimes would be mapped: torch's bundled one and /opt/rocm's); import torch first, or keep the process torch-free")
 
 
 def load():
@@ -129,6 +149,7 @@ EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_des
 
 FLOWKP_DTYPE = np.dtype([("label", "<i4"), ("x", "<i4"), ("y", "<i4"), ("score", "<f4")], align=True)
 E_REFERENCE_RAISES = -7
+E_RANGE = -8
 
 
 def debug(key, value=0, out=None):
@@ -150,8 +171,13 @@ def _fp(a):
 
 
 def default_config(**kw):
+    """eagle_default_config + overrides.  The library's default is the split family with the detector in the exact fp32 family
+    (``det_precision = EAGLE_PREC_F32 + 1``); a caller that picks another ``precision`` without naming ``det_precision`` gets the
+    detector in that same family (``det_precision = 0``)."""
     cfg = EagleConfig()
     load().eagle_default_config(C.byref(cfg))
+    if "precision" in kw and kw["precision"] != PREC_F32S and "det_precision" not in kw:
+        kw = dict(kw, det_precision=0)
     for k, v in kw.items():
         if k == "det_variant" and isinstance(v, str):
             v = DET_VARIANTS[v]
@@ -168,13 +194,24 @@ class Handle:
         self.L = load()
         self.cfg = cfg or default_config(**kw)
         self._h = C.c_void_p()
+        global _gpu_touched
+        _gpu_touched = True
         rc = self.L.eagle_create(C.byref(self.cfg), C.byref(self._h))
         if rc:
             raise EagleError(f"eagle_create failed ({rc}): {self.L.eagle_last_error(None).decode()}")
 
     def _check(self, rc, what):
+        if rc == E_RANGE:
+            raise EagleRangeError(f"{what}: {self.L.eagle_last_error(self._h).decode()}")
         if rc:
             raise EagleError(f"{what} failed ({rc}): {self.L.eagle_last_error(self._h).decode()}")
+
+    def _check_records(self, rc, what, out):
+        try:
+            self._check(rc, what)
+        except EagleRangeError as e:
+            e.records = out
+            raise
 
     def close(self):
         if self._h:
@@ -195,17 +232,19 @@ class Handle:
     def finalize_weights(self):
         self._check(self.L.eagle_finalize_weights(self._h), "finalize_weights")
 
-    def process(self, frames):
-        """frames: uint8 [n,h,w,3] BGR (host).  -> structured array [n] of RESULT_DTYPE."""
+    def process(self, frames, out=None):
+        """frames: uint8 [n,h,w,3] BGR (host).  -> structured array [n] of RESULT_DTYPE (``out``: optional preallocated result array)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         if frames.ndim == 3:
             frames = frames[None]
         n, h, w, c = frames.shape
         if (h, w, c) != (self.cfg.frame_h, self.cfg.frame_w, 3):
             raise EagleError(f"frame shape {(h, w, c)} does not match the handle ({self.cfg.frame_h}, {self.cfg.frame_w}, 3)")
-        out = np.zeros(n, RESULT_DTYPE)
-        self._check(self.L.eagle_process_frames(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, 0, 0,
-                                                out.ctypes.data_as(C.c_void_p)), "process_frames")
+        if out is None:
+            out = np.zeros(n, RESULT_DTYPE)
+        assert out.dtype == RESULT_DTYPE and len(out) >= n and out.flags.c_contiguous
+        self._check_records(self.L.eagle_process_frames(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, 0, 0,
+                                                        out.ctypes.data_as(C.c_void_p)), "process_frames", out)
         return out
 
     def host_frames(self, n):
@@ -238,7 +277,7 @@ class Handle:
     def process_device(self, dptr, n, out=None):
         if out is None:
             out = np.zeros(n, RESULT_DTYPE)
-        self._check(self.L.eagle_process_device_frames(self._h, dptr, n, out.ctypes.data_as(C.c_void_p)), "process_device_frames")
+        self._check_records(self.L.eagle_process_device_frames(self._h, dptr, n, out.ctypes.data_as(C.c_void_p)), "process_device_frames", out)
         return out
 
     def reproject(self, recs, Hs, flags):

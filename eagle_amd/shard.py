@@ -29,10 +29,11 @@ def _pad(local, c):
     return out
 
 
-def gather_records(local, n_frames, rank, world, handle=None, transport="rccl", out=None):
+def gather_records(local, n_frames, rank, world, handle=None, transport="rccl", out=None, force=False):
     """local: this rank's records (structured array).  Returns all ``n_frames`` records in frame order on every rank.
-    ``out``: optional preallocated (and pre-touched) [chunk_size*world] result buffer, used when no rank is ragged."""
-    if world == 1:
+    ``out``: optional preallocated (and pre-touched) [chunk_size*world] result buffer, used when no rank is ragged.
+    ``force``: run the collective even at world 1 (bench.py --force-multirank-path: the one-GPU test of the N > 1 code path)."""
+    if world == 1 and not force:
         return np.ascontiguousarray(local)
     c = chunk_size(n_frames, world)
     padded = _pad(local, c)
@@ -41,6 +42,8 @@ def gather_records(local, n_frames, rank, world, handle=None, transport="rccl", 
             raise ValueError("transport='rccl' needs the library handle (eagle_comm_init must have been called)")
         allr = handle.gather(padded, world, out if (out is not None and len(out) == c * world) else None)
     elif transport == "dist":
+        from . import lib
+        lib.require_torch_first()
         import torch
         import torch.distributed as dist
         raw = torch.from_numpy(padded.view(np.uint8).reshape(-1).copy())
@@ -62,9 +65,10 @@ def gather_records(local, n_frames, rank, world, handle=None, transport="rccl", 
 
 def init_rccl(handle, rank, world):
     """Bootstrap the library's RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed broadcasts it."""
+    from . import lib
+    lib.require_torch_first()
     import torch
     import torch.distributed as dist
-    from . import lib
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         uid = torch.frombuffer(bytearray(lib.comm_unique_id()), dtype=torch.uint8).clone()

@@ -30,6 +30,8 @@ extern "C" {
 #define EAGLE_E_MISSING (-4)   /* a required weight tensor was never loaded */
 #define EAGLE_E_NOKERNEL (-5)  /* no kernel instance for a layer shape */
 #define EAGLE_E_COMM (-6)      /* RCCL error */
+#define EAGLE_E_RANGE (-8)     /* EAGLE_PREC_F32S: activations left the tensor format's range (|v| > 4094) and were clipped.  The records ARE written
+                                  (EagleFrameResult.pad[1] = 1 marks the frames) but are not fp32-grade; see EagleConfig.allow_saturation */
 
 #define EAGLE_MAX_DET 300      /* ultralytics max_det */
 #define EAGLE_N_LANDMARKS 57   /* eagle/utils/pitch.py:1-60 */
@@ -65,9 +67,12 @@ typedef struct EagleConfig {
     int32_t ransac_max_iters;  /* 2000  cv2 default */
     int32_t lm_iters;          /* 10    cv2 default */
     int32_t use_graph;         /* 1: capture the per-batch step into a hipGraph and replay it */
-    int32_t det_precision;     /* 0: the detector runs in `precision`; otherwise EAGLE_PREC_* + 1 for the detector alone (e.g. EAGLE_PREC_F32S + 1 in an
-                                  EAGLE_PREC_F16 handle: boxes, confidences, NMS order and ids at fp32 grade for 1.4 % of the FLOPs, key-points in fp16) */
-    int32_t reserved[6];
+    int32_t det_precision;     /* 0: the detector runs in `precision`; otherwise EAGLE_PREC_* + 1 for the detector alone.  eagle_default_config sets
+                                  EAGLE_PREC_F32 + 1: key-points in the split family, the detector (1.4 % of the FLOP with yolov8n) in the exact fp32
+                                  family, so that boxes, confidences, classes, NMS order and detection-index ids are the fp32 oracle's bit for bit */
+    int32_t allow_saturation;  /* EAGLE_PREC_F32S: 0 (default): a call in which an activation store was clipped at +-4094 returns EAGLE_E_RANGE;
+                                  1: it returns EAGLE_OK and only flags the frames (EagleFrameResult.pad[1]) and counts them (EagleTimings) */
+    int32_t reserved[5];
 } EagleConfig;
 
 typedef struct EagleDet {      /* one row of boxes.xyxy/.conf/.cls after NMS (cm.py:569-572) + cm.py:598-627 */
@@ -101,7 +106,7 @@ typedef struct EagleFrameResult {
     int32_t n_candidates;      /* boxes above detector_floor before NMS */
     uint8_t H_valid;
     uint8_t bounds_valid;
-    uint8_t pad[2];
+    uint8_t pad[2];            /* pad[0]: clip sessions, see eagle_clip_fetch; pad[1] = 1: EAGLE_PREC_F32S clipped an activation of this frame (EAGLE_E_RANGE) */
     double H[9];               /* row-major, h33 = 1 */
     double bounds[4];          /* x of [bottom_left(y=0), top_left(68), top_right(68), bottom_right(0)] */
     int32_t hm_idx[EAGLE_N_LANDMARKS];   /* first-maximum flat index per heat-map (kh.py:588) */
@@ -208,7 +213,9 @@ int eagle_track_frames_cmc(EagleHandle* h, EagleFrameResult* recs, int n, const 
  * before eagle_finalize_weights, EAGLE_E_STATE otherwise.  eagle_track_frames_reid: as eagle_track_frames_cmc with the embeddings of each
  * record's high-confidence detections: record i owns feat_count[i] consecutive rows of `feats`, feat_det lists their detection indices.  The
  * association then is BoT-SORT's: cost = min(IoU distance, embedding distance / 2) with embedding distances above appearance_thresh 0.25 or IoU
- * distances above proximity_thresh 0.5 set to 1; track features are exponential moving averages (alpha 0.9) of the normalised embeddings. */
+ * distances above proximity_thresh 0.5 set to 1; track features are exponential moving averages (alpha 0.9) of the normalised embeddings.
+ * Contract: `feats` holds sum(feat_count) rows of EAGLE_REID_DIM floats and `feat_det` as many entries; 0 <= feat_count[i] <= EAGLE_MAX_DET and
+ * 0 <= feat_det[.] < recs[i].n_det are checked (EAGLE_E_INVALID) before anything is read. */
 #define EAGLE_REID_DIM 512
 int eagle_reid_features(EagleHandle* h, const void* d_bgr, int n_frames, const EagleCrop* crops, int n_crops, float* feats);
 int eagle_track_frames_reid(EagleHandle* h, EagleFrameResult* recs, int n, const double* warps /* NULL: none */, const float* feats,
@@ -232,7 +239,9 @@ typedef struct EagleTimings {
     int32_t n_launches;
     int32_t n_conv_launches;
     double conv_flop;          /* algorithmic FLOP of the convolutions of the last call (2*MAC) */
-    int32_t reserved[8];
+    int32_t sat_events;        /* EAGLE_PREC_F32S: lane-level activation stores of the last eagle_process_* / eagle_clip_fetch call that were clipped at +-4094 */
+    int32_t sat_frames;        /* ... and the number of frames they occurred in (0 / 0 in every healthy run) */
+    int32_t reserved[6];
 } EagleTimings;
 int eagle_set_profiling(EagleHandle* h, int per_kernel_events);
 int eagle_get_timings(EagleHandle* h, EagleTimings* t);

@@ -23,9 +23,7 @@ F32 = np.float32
 def preprocess(frame_bgr, scale=0.15):
     """boxmot BaseCMC.preprocess: cvtColor(BGR2GRAY) then cv2.resize(img, (0, 0), fx=scale, fy=scale, INTER_LINEAR) (dsize = round(size * scale))"""
     g = P.bgr2gray(frame_bgr)
-    sh, sw = g.shape
-    dh, dw = int(np.rint(sh * scale)), int(np.rint(sw * scale))
-    return P.resize_linear_u8c3(np.repeat(g[:, :, None], 3, axis=2), dh, dw)[:, :, 0].copy()
+    return P.resize_linear_u8c3_fxfy(np.repeat(g[:, :, None], 3, axis=2), scale, scale)[:, :, 0].copy()
 
 
 def gradients(img):

@@ -182,9 +182,8 @@ void eo_heatmap_argmax(const float* logits, int HW, int Cs, int C, int32_t* idx,
 /*  - otherwise half-pixel centres, 11-bit coefficients, cv2's 8u vertical pass rounding.                  */
 /* src [sh,sw,3] (row stride in bytes), dst [dh,dw,3] dense.                                               */
 /* ---------------------------------------------------------------------------------------------------- */
-static void eo_lin_coef(int dsize, int ssize, int* ofs, short* co)
+static void eo_lin_coef_scaled(int dsize, int ssize, double scale, int* ofs, short* co)
 {
-    const double scale = (double)ssize / dsize;
     for (int d = 0; d < dsize; ++d) {
         float f = (float)((d + 0.5) * scale - 0.5);
         int s = (int)floorf(f);
@@ -195,6 +194,13 @@ static void eo_lin_coef(int dsize, int ssize, int* ofs, short* co)
         co[2 * d] = (short)lrintf((1.f - f) * 2048.f);
         co[2 * d + 1] = (short)lrintf(f * 2048.f);
     }
+}
+static void eo_resize_linear_general(const uint8_t* src, int sh, int sw, int64_t sstride, uint8_t* dst, int dh, int dw, double scale_x, double scale_y);
+/* cv2.resize(src, (0, 0), fx, fy, INTER_LINEAR): dsize = round(ssize * f) is the caller's, the coordinate map uses 1 / fx and 1 / fy (OpenCV keeps
+   inv_scale = fx when dsize is empty and only derives it from dsize / ssize when dsize is given) */
+void eo_resize_linear_u8c3_fxfy(const uint8_t* src, int sh, int sw, int64_t sstride, uint8_t* dst, int dh, int dw, double fx, double fy)
+{
+    eo_resize_linear_general(src, sh, sw, sstride, dst, dh, dw, 1.0 / fx, 1.0 / fy);
 }
 void eo_resize_linear_u8c3(const uint8_t* src, int sh, int sw, int64_t sstride, uint8_t* dst, int dh, int dw)
 {
@@ -211,10 +217,14 @@ void eo_resize_linear_u8c3(const uint8_t* src, int sh, int sw, int64_t sstride, 
                 }
         return;
     }
+    eo_resize_linear_general(src, sh, sw, sstride, dst, dh, dw, (double)sw / dw, (double)sh / dh);
+}
+static void eo_resize_linear_general(const uint8_t* src, int sh, int sw, int64_t sstride, uint8_t* dst, int dh, int dw, double scale_x, double scale_y)
+{
     int* xo = (int*)malloc(sizeof(int) * dw); short* xc = (short*)malloc(sizeof(short) * 2 * dw);
     int* yo = (int*)malloc(sizeof(int) * dh); short* yc = (short*)malloc(sizeof(short) * 2 * dh);
-    eo_lin_coef(dw, sw, xo, xc);
-    eo_lin_coef(dh, sh, yo, yc);
+    eo_lin_coef_scaled(dw, sw, scale_x, xo, xc);
+    eo_lin_coef_scaled(dh, sh, scale_y, yo, yc);
     for (int y = 0; y < dh; ++y) {
         const int y0 = yo[y], y1 = (y0 + 1 < sh) ? y0 + 1 : y0;
         const int b0 = yc[2 * y], b1 = yc[2 * y + 1];

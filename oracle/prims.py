@@ -107,6 +107,17 @@ def resize_linear_u8c3(src, dh, dw):
     return dst
 
 
+def resize_linear_u8c3_fxfy(src, fx, fy):
+    """cv2.resize(src, (0, 0), fx=fx, fy=fy, interpolation=INTER_LINEAR): dsize = round(size * f), coordinates mapped with 1 / f"""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw, c = src.shape
+    assert c == 3
+    dh, dw = int(np.rint(sh * fy)), int(np.rint(sw * fx))
+    dst = np.empty((dh, dw, 3), np.uint8)
+    lib().eo_resize_linear_u8c3_fxfy(_p(src, C.c_uint8), sh, sw, C.c_int64(sw * 3), _p(dst, C.c_uint8), dh, dw, C.c_double(fx), C.c_double(fy))
+    return dst
+
+
 def yolo_decode_level(box, cls, nc, stride):
     """box [gh,gw,>=64] logits, cls [gh,gw,>=nc] logits -> [gh*gw, 4+nc]"""
     box = _f32(box); cls = _f32(cls)

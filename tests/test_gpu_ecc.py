@@ -135,6 +135,40 @@ def test_coordinate_model_with_ecc_motion_equals_the_tracker_fed_with_oracle_war
     assert np.abs(w1[1:] - IDENT).max() > 1e-3             # the estimator did something on these frames
 
 
+def test_coordinate_model_carries_the_ecc_template_across_clips_and_resets_it():
+    """boxmot's ECC object lives inside the tracker, so clip k+1's first frame is aligned to clip k's last frame.  CoordinateModel used to
+    open the tracker lazily AFTER the clip's motion estimate — eagle_track_open forgets the template, so the first clip's template was thrown away
+    and the second clip's frame 0 got the identity.  Two clips through get_coordinates (both cadences), the warps the model obtained captured at the
+    handle: they equal ONE oracle estimator fed with all frames in order; after reset_tracker() the next clip starts from the identity again."""
+    from eagle_amd.coordinate_model import CoordinateModel
+    a = [synth.frame(0, t) for t in range(4)]
+    b = [synth.frame(0, t) for t in range(9, 13)]             # the camera has moved on between the clips
+    for cadence in ({"fps": 1}, {"fps": 24, "num_keypoint_detection": 3}):
+        cm = CoordinateModel(batch=2, tracker=True, camera_motion="ecc", detector_conf=0.2)
+        seen = []
+        inner = cm.handle.clip_motion_ecc
+
+        def spy(*args, **kw):
+            w = inner(*args, **kw)
+            seen.append(np.array(w[0] if isinstance(w, tuple) else w))
+            return w
+        cm.handle.clip_motion_ecc = spy
+        cm.get_coordinates(np.stack(a), **cadence)
+        cm.get_coordinates(np.stack(b), **cadence)
+        cm.reset_tracker()
+        cm.get_coordinates(np.stack(b), **cadence)
+        cm.handle.close()
+        assert len(seen) == 3 and all(w.shape == (4, 6) for w in seen), [w.shape for w in seen]
+        e = ecc.ECC()
+        exp = np.stack([e.apply(f).astype(np.float64).reshape(6) for f in a + b])
+        assert _close(seen[0], exp[:4]) and _close(seen[1], exp[4:]), (cadence, seen[1][0], exp[4])
+        assert np.abs(exp[4] - IDENT).max() > 1e-3, "the clips must differ at the boundary for this test to mean anything"
+        assert np.abs(seen[1][0] - IDENT).max() > 1e-3       # clip 2, frame 0: aligned to clip 1's last frame, not the identity
+        e2 = ecc.ECC()
+        assert _close(seen[2], np.stack([e2.apply(f).astype(np.float64).reshape(6) for f in b]))      # fresh estimator after the reset
+        assert np.array_equal(seen[2][0], IDENT)
+
+
 def test_bad_arguments_and_degenerate_ranges():
     from eagle_amd.coordinate_model import CoordinateModel
     h = _handle()

@@ -268,6 +268,52 @@ def test_conv_split_8x48_tile(shape, res, post, monkeypatch):
     assert err < F32S_TOL, f"split 8x48-tile conv error {err}"
 
 
+def test_conv_split_k_split_exchange_is_reproducible_beside_f16_mfma_waves(state_dicts):
+    """VERDICT r3 task 3b.  The K-split A-direct instances (variant 15: every 3x3 stride-2 layer with Cout = 96 k of the split family, e.g.
+    HRNet's 48 -> 96 @135x240 -> 68x120) exchange fp32 partial accumulators between the waves of a pair.  Until round 4 that exchange was a
+    f32x4 addition = v_pk_add_f32, the instruction class DESIGN.md §8c found unreliable when f16-MFMA-heavy waves share the SIMD; it is scalar
+    now (tests/test_isa_guard.py).  Here: the layer, with a residual, 200 times while a second handle runs the fp16 networks on another
+    thread — every repeat byte-identical to the first (taken on an idle GPU) and within F32S_TOL of the fp32 oracle."""
+    import threading
+    from eagle_amd import lib, synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    from oracle import prims as P
+    hs, ys = state_dicts
+    x = np.maximum(_rand((2, 135, 240, 48), 41), 0)
+    wt = _rand((3, 3, 48, 96), 42, (2.0 / (48 * 9)) ** 0.5)
+    b = _rand((96,), 43, 0.1)
+    r1 = _rand((2, 68, 120, 96), 44)
+    first = lib.op_conv2d(x, wt, b, 2, 0, r1, None, 1, lib.PREC_F32S)            # idle GPU
+    ref = P.conv2d(_split_round(x), wt, b, stride=2, pre=0, r1=_split_round(r1), r2=None, post=1)
+    assert np.abs(first - ref).max() <= F32S_TOL * np.abs(ref).max()
+    co = CoordinateModel(precision="f16", batch=8, hrnet_state_dict=hs, detector_state_dict=ys)
+    busy_frames = synth.clip(0, 8)
+    stop, batches, err = [False], [0], []
+
+    def busy():
+        try:
+            while not stop[0]:
+                co.process_records(busy_frames)
+                batches[0] += 1
+        except Exception as e:                       # pragma: no cover
+            err.append(repr(e))
+
+    t = threading.Thread(target=busy)
+    t.start()
+    try:
+        bad = 0
+        for k in range(200):
+            got = lib.op_conv2d(x, wt, b, 2, 0, r1, None, 1, lib.PREC_F32S)
+            bad += int(got.tobytes() != first.tobytes())
+    finally:
+        stop[0] = True
+        t.join()
+        co.handle.close()
+    assert not err, err
+    assert batches[0] >= 3, f"the co-runner finished only {batches[0]} batches: no overlap was exercised"
+    assert bad == 0, f"{bad} of 200 repeats differ from the idle-GPU result"
+
+
 def test_conv_split_saturates_instead_of_overflowing():
     """An output beyond the split format's range (|v| > 4094) clips to +-65504 / 16 instead of becoming inf (and NaN one layer later)."""
     from eagle_amd import lib

@@ -466,7 +466,7 @@ def test_f32s_family_equals_fp32_oracle_random_head(state_dicts, frames, oracle_
     noise-like heat-maps, H mostly unsolvable) — same fixtures, same oracle steps as test_f32_path_identical_to_oracle."""
     from eagle_amd.coordinate_model import CoordinateModel
     hs, ys = state_dicts
-    cm = CoordinateModel(precision="f32s", batch=2, hrnet_state_dict=hs, detector_state_dict=ys)
+    cm = CoordinateModel(precision="f32s", detector_precision="f32s", batch=2, hrnet_state_dict=hs, detector_state_dict=ys)
     recs = cm.process_records(frames)
     cm.handle.close()
     tot = [_f32s_record_parity(recs[i], oref, aux, f"f32s random head frame {i}", (720, 1280)) for i, (oref, aux) in enumerate(oracle_steps)]
@@ -488,7 +488,7 @@ def test_f32s_family_equals_fp32_oracle_peaked_head_cfg2(state_dicts):
     hs, ys = state_dicts
     hs2, g = _peaked_state_dict(hs)
     frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 4), synth.frame(0, 9), synth.frame(0, 1), synth.frame(0, 6), synth.frame(0, 14)])
-    cm = CoordinateModel(precision="f32s", batch=4, hrnet_state_dict=hs2, detector_state_dict=ys)
+    cm = CoordinateModel(precision="f32s", detector_precision="f32s", batch=4, hrnet_state_dict=hs2, detector_state_dict=ys)
     recs = cm.process_records(frames)
     cm.handle.close()
     ora = pipeline.OracleModel(hs2, ys, backend="c")
@@ -504,21 +504,15 @@ def test_f32s_family_equals_fp32_oracle_peaked_head_cfg2(state_dicts):
     assert sum(t["conf_tie"] for t in tot) <= 0.02 * sum(t["dets"] for t in tot), tot
 
 
-def test_f32s_family_equals_fp32_oracle_cfg3():
-    """cfg 3: 1920x1080, yolov8l@960 (103 convolutions deep) + HRNet-W48 with the peaked head."""
-    from eagle_amd import synth, weights
+def test_f32s_family_equals_fp32_oracle_cfg3(cfg3_case):
+    """cfg 3: 1920x1080, yolov8l@960 (103 convolutions deep) + HRNet-W48 with the peaked head, BOTH networks in the split family."""
     from eagle_amd.coordinate_model import CoordinateModel
-    from oracle import pipeline
-    hs, yl = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("l", 0)
-    hs2, g = _peaked_state_dict(hs)
-    frames3 = np.stack([synth.frame(int(g["design"][0]), int(g["design"][1]), 1080, 1920), synth.frame(0, 9, 1080, 1920), synth.frame(2, 5, 1080, 1920)])
-    cm = CoordinateModel(precision="f32s", batch=2, frame_hw=(1080, 1920), detector="l", det_imgsz=960, hrnet_state_dict=hs2, detector_state_dict=yl)
+    hs2, yl, frames3, steps = cfg3_case
+    cm = CoordinateModel(precision="f32s", detector_precision="f32s", batch=2, frame_hw=(1080, 1920), detector="l", det_imgsz=960, hrnet_state_dict=hs2, detector_state_dict=yl)
     recs = cm.process_records(frames3)
     cm.handle.close()
-    ora = pipeline.OracleModel(hs2, yl, variant="l", imgsz=960, backend="c")
     tot = []
-    for i, frame in enumerate(frames3):
-        oref, aux = ora.step(frame, i)
+    for i, (oref, aux) in enumerate(steps):
         tot.append(_f32s_record_parity(recs[i], oref, aux, f"f32s cfg3 frame {i}", (1080, 1920), conf_tol=6e-5, box_tol=1e-2, score_tol=3e-5))
     print("f32s parity (cfg3):", tot)
     assert tot[0]["h_identical"] and sum(t["hm_tie"] + t["near_int_box"] for t in tot) <= 1, tot
@@ -538,7 +532,7 @@ def test_f32s_ids_identical_with_a_sparse_detector(state_dicts):
     for l in range(3):
         ys2[f"model.22.cv3.{l}.2.bias"] = (ys[f"model.22.cv3.{l}.2.bias"] - np.float32(1.25)).astype(np.float32)
     frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 9), synth.frame(2, 5)])
-    cm = CoordinateModel(precision="f32s", batch=3, hrnet_state_dict=hs2, detector_state_dict=ys2)
+    cm = CoordinateModel(precision="f32s", detector_precision="f32s", batch=3, hrnet_state_dict=hs2, detector_state_dict=ys2)
     recs = cm.process_records(frames)
     cm.handle.close()
     ora = pipeline.OracleModel(hs2, ys2, backend="c")
@@ -549,6 +543,136 @@ def test_f32s_ids_identical_with_a_sparse_detector(state_dicts):
     print("f32s parity (sparse detector):", tot)
     assert all(3 <= t["dets"] <= 120 for t in tot), [t["dets"] for t in tot]
     assert sum(t["hm_tie"] + t["near_int_box"] + t["conf_tie"] for t in tot) == 0, tot
+
+
+# ---- the DEFAULT handle (round 4): key-points in the split family, detector in the exact fp32 family (EagleConfig::det_precision) ---------------
+def _default_handle_parity(rec, oref, aux, tag, frame_hw, score_tol=5e-6):
+    """north_star's integer contract WITHOUT an admitted exception: every detection field of the record — float box, confidence, class, NMS
+    position (= detection-index id, cm.py:598-627), integer box, foot point — equals the fp32 oracle's (OracleModel(backend="c"), pinned to the
+    reference) under np.array_equal; heat-map maxima, key-point pixels, synthesised points and H_valid equal, H bit-identical, pitch integers equal."""
+    from eagle_amd import records
+    from eagle_amd.pitch import INTERSECTION_TO_PITCH_POINTS
+    dets = aux["dets"]
+    n = int(rec["n_det"])
+    assert n == len(dets), f"{tag}: {n} detections vs {len(dets)}"
+    got = np.stack([rec["det"][k][:n] for k in ("x1", "y1", "x2", "y2", "conf")], 1)
+    assert np.array_equal(got, dets[:, :5].astype(np.float32)), f"{tag}: float boxes / confidences differ at {np.argwhere(got != dets[:, :5])[:3]}"
+    cls = dets[:, 5].astype(np.int32)
+    assert np.array_equal(rec["det"]["cls"][:n], cls), f"{tag}: classes differ"
+    ids = np.full(n, -1, np.int32)                          # cm.py:598-627: persons keyed by detection index, balls by enumerate index
+    ids[(cls == 0) | (cls == 1)] = np.nonzero((cls == 0) | (cls == 1))[0]
+    ids[cls == 2] = np.arange(int((cls == 2).sum()))
+    assert np.array_equal(rec["det"]["id"][:n], ids), f"{tag}: ids differ"
+    fh, fw = frame_hw
+    bi = dets[:, :4].astype(np.int64)                       # astype(int) truncation (cm.py:600), persons clipped to the frame
+    person = (cls == 0) | (cls == 1)
+    bi[person, 0::2] = np.clip(bi[person, 0::2], 0, fw - 1); bi[person, 1::2] = np.clip(bi[person, 1::2], 0, fh - 1)
+    gi = np.stack([rec["det"][k][:n] for k in ("bx1", "by1", "bx2", "by2")], 1).astype(np.int64)
+    assert np.array_equal(gi, bi), f"{tag}: integer boxes differ at {np.argwhere(gi != bi)[:3]}"
+    # key-point half (split family): integers identical, scores to a few 1e-6
+    assert np.array_equal(rec["hm_idx"], aux["hm_idx"]), f"{tag}: heat-map maxima differ on channels {np.nonzero(rec['hm_idx'] != aux['hm_idx'])[0]}"
+    assert float(np.abs(rec["hm_score"].astype(np.float64) - aux["hm_score"]).max()) <= score_tol
+    allkp = {INTERSECTION_TO_PITCH_POINTS[int(k["label"])]: (int(k["x"]), int(k["y"])) for k in rec["kp"][: int(rec["n_kp"])]}
+    assert allkp == {k: (int(v[0]), int(v[1])) for k, v in aux["kp_synth"].items()}, f"{tag}: key-points differ"
+    assert bool(rec["H_valid"]) == (aux["H"] is not None), f"{tag}: H validity differs"
+    if aux["H"] is not None:
+        assert np.array_equal(rec["H"].reshape(3, 3), aux["H"]), f"{tag}: H differs"
+    assert not rec["pad"][1], f"{tag}: saturation flag set"
+    # the reference-schema record: keys (ids), integer boxes, pitch integers, None-ness identical; confidences bit-equal
+    got_d, ref_d = _canon_keep(records.to_reference_dict(rec, 0)), _canon_keep(oref)
+    assert got_d["Coordinates"] == ref_d["Coordinates"], f"{tag}: Coordinates differ"
+    assert got_d["Keypoints"] == ref_d["Keypoints"] and got_d["Boundaries"] == ref_d["Boundaries"], f"{tag}: Keypoints / Boundaries differ"
+    return n
+
+
+def test_default_handle_dense_detector_is_exception_free_cfg2(state_dicts, frames, oracle_steps):
+    """VERDICT r3 task 1b: the five random-head cfg-2 frames (240 - 300 boxes each, confidences ~1e-3 apart — the detector on which the split
+    family swaps a few near-tie ids) through the DEFAULT configuration: no conf_tie / near_int_box branch exists in this comparison."""
+    from eagle_amd import lib
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    cm = CoordinateModel(batch=2, hrnet_state_dict=hs, detector_state_dict=ys)          # all defaults: precision f32s, detector exact fp32
+    assert cm.handle.cfg.precision == lib.PREC_F32S and cm.handle.cfg.det_precision == lib.PREC_F32 + 1
+    recs = cm.process_records(frames)
+    cm.handle.close()
+    nd = [_default_handle_parity(recs[i], oref, aux, f"default handle cfg2 frame {i}", (720, 1280)) for i, (oref, aux) in enumerate(oracle_steps)]
+    print("default handle, cfg2, detections per frame:", nd)
+    assert sum(nd) > 1000, nd
+
+
+@pytest.fixture(scope="module")
+def cfg3_case():
+    """Three 1920x1080 frames, yolov8l@960 + HRNet with the peaked head, and the fp32 oracle's steps (shared by the cfg-3 tests)."""
+    from eagle_amd import synth, weights
+    from oracle import pipeline
+    hs, yl = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("l", 0)
+    hs2, g = _peaked_state_dict(hs)
+    frames3 = np.stack([synth.frame(int(g["design"][0]), int(g["design"][1]), 1080, 1920), synth.frame(0, 9, 1080, 1920), synth.frame(2, 5, 1080, 1920)])
+    ora = pipeline.OracleModel(hs2, yl, variant="l", imgsz=960, backend="c")
+    return hs2, yl, frames3, [ora.step(f, i) for i, f in enumerate(frames3)]
+
+
+def test_default_handle_dense_detector_is_exception_free_cfg3(cfg3_case):
+    """The same on cfg 3 (1920x1080, yolov8l@960: 103 convolutions deep, where the split family's confidences move by 4e-5)."""
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs2, yl, frames3, steps = cfg3_case
+    cm = CoordinateModel(batch=2, frame_hw=(1080, 1920), detector="l", det_imgsz=960, hrnet_state_dict=hs2, detector_state_dict=yl)
+    recs = cm.process_records(frames3)
+    cm.handle.close()
+    nd = [_default_handle_parity(recs[i], oref, aux, f"default handle cfg3 frame {i}", (1080, 1920), score_tol=3e-5) for i, (oref, aux) in enumerate(steps)]
+    print("default handle, cfg3, detections per frame:", nd)
+    assert sum(nd) > 100, nd
+
+
+def test_default_handle_detector_half_equals_the_exact_family(state_dicts, frames):
+    """GPU against GPU: every detection field of the default handle is byte-identical to the exact (fp32) handle's."""
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    a = CoordinateModel(batch=3, hrnet_state_dict=hs, detector_state_dict=ys)
+    ra = a.process_records(frames); a.handle.close()
+    b = CoordinateModel(precision="f32", batch=3, hrnet_state_dict=hs, detector_state_dict=ys)
+    rb = b.process_records(frames); b.handle.close()
+    assert ra["n_det"].tolist() == rb["n_det"].tolist() and ra["n_candidates"].tolist() == rb["n_candidates"].tolist()
+    for f in ("x1", "y1", "x2", "y2", "conf", "cls", "bx1", "by1", "bx2", "by2", "id", "foot_x", "foot_y", "reported"):
+        assert ra["det"][f].tobytes() == rb["det"][f].tobytes(), f
+
+
+# ---- f32s fails loudly (round 4): the split format clips at +-4094 and says so ---------------------------------------------------------------
+def test_f32s_saturation_is_reported_not_silent(state_dicts, frames):
+    """VERDICT r3 task 3a.  Stem weights scaled x4096 push activations beyond the split format's range: the call must return EAGLE_E_RANGE
+    (EagleRangeError), count the clipped stores, flag the frames (pad[1]) and still hand the records over; allow_saturation turns the error
+    into flags only; the unscaled network reports 0 / 0 and no flag."""
+    from eagle_amd import lib
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    ok = CoordinateModel(batch=2, hrnet_state_dict=hs, detector_state_dict=ys)
+    r = ok.process_records(frames[:3])
+    t = ok.handle.timings()
+    assert (t.sat_events, t.sat_frames) == (0, 0) and not r["pad"][:, 1].any()
+    ok.handle.close()
+    hot = dict(hs)
+    k = "unnormalized_model.0.conv1.weight"
+    hot[k] = (hs[k] * np.float32(4096.0)).astype(np.float32)
+    cm = CoordinateModel(batch=2, hrnet_state_dict=hot, detector_state_dict=ys)
+    with pytest.raises(lib.EagleRangeError) as ei:
+        cm.process_records(frames[:3])
+    assert "4094" in str(ei.value) and ei.value.records is not None and len(ei.value.records) == 3
+    t = cm.handle.timings()
+    assert t.sat_events > 0 and t.sat_frames == 3, (t.sat_events, t.sat_frames)
+    assert ei.value.records["pad"][:, 1].all()
+    # the exact-family detector half of the flagged records is untouched by the key-point network's clipping
+    assert ei.value.records["n_det"].tolist() == r["n_det"].tolist()
+    cm.handle.close()
+    cm2 = CoordinateModel(batch=2, hrnet_state_dict=hot, detector_state_dict=ys, allow_saturation=True)
+    r2 = cm2.process_records(frames[:3])
+    t2 = cm2.handle.timings()
+    assert r2["pad"][:, 1].all() and t2.sat_events == t.sat_events and t2.sat_frames == 3
+    cm2.handle.close()
+    # a fp32 handle has no such range: same weights, no report
+    cm3 = CoordinateModel(precision="f32", batch=2, hrnet_state_dict=hot, detector_state_dict=ys)
+    r3 = cm3.process_records(frames[:1])
+    assert cm3.handle.timings().sat_events == 0 and not r3["pad"][:, 1].any()
+    cm3.handle.close()
 
 
 def test_f32s_full_size_clip_properties(state_dicts):
@@ -680,7 +804,7 @@ def test_mixed_handle_detector_records_equal_the_f32s_family(state_dicts, frames
     half (same kernels, same tensors), for 1.4 % of the FLOPs."""
     from eagle_amd.coordinate_model import CoordinateModel
     hs, ys = state_dicts
-    a = CoordinateModel(precision="f32s", batch=2, hrnet_state_dict=hs, detector_state_dict=ys)
+    a = CoordinateModel(precision="f32s", detector_precision="f32s", batch=2, hrnet_state_dict=hs, detector_state_dict=ys)
     ra = a.process_records(frames)
     a.handle.close()
     b = CoordinateModel(precision="f16", detector_precision="f32s", batch=2, hrnet_state_dict=hs, detector_state_dict=ys)

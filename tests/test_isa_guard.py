@@ -47,15 +47,15 @@ def _code_objects(tmp_path):
     return out
 
 
-@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(f"{LLVM}/llvm-objdump")), reason="library or llvm tools not present")
-def test_no_packed_fp32_arithmetic_in_bit_exact_kernels(tmp_path):
+def _scan(tmp_path, want_of):
+    """(kernel names seen, [(kernel, instruction)] packed-fp32 offenders) over the functions want_of(all functions of a code object) selects."""
     cos = _code_objects(tmp_path)
     assert len(cos) >= 10, "expected one gfx950 code object per translation unit"
     seen, offenders = set(), []
     for co in cos:
         syms = subprocess.run([f"{LLVM}/llvm-readelf", "-s", "--wide", str(co)], capture_output=True, text=True, check=True).stdout
         funcs = [ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln]
-        want = [f for f in funcs if any(g in f for g in GUARDED) and not f.endswith(".kd")]
+        want = [f for f in want_of(funcs) if not f.endswith(".kd")]
         if not want:
             continue
         dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", f"--disassemble-symbols={','.join(want)}", str(co)],
@@ -65,10 +65,35 @@ def test_no_packed_fp32_arithmetic_in_bit_exact_kernels(tmp_path):
             m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
             if m:
                 cur = m.group(1)
-                seen.update(g for g in GUARDED if g in cur)
+                seen.add(cur)
                 continue
             if cur and PACKED.search(ln):
                 offenders.append((cur, ln.strip()))
-    missing = [g for g in GUARDED if g not in seen]
+    return seen, offenders
+
+
+needs_lib = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(f"{LLVM}/llvm-objdump")), reason="library or llvm tools not present")
+
+
+@needs_lib
+def test_no_packed_fp32_arithmetic_in_bit_exact_kernels(tmp_path):
+    seen, offenders = _scan(tmp_path, lambda funcs: [f for f in funcs if any(g in f for g in GUARDED)])
+    missing = [g for g in GUARDED if not any(g in s for s in seen)]
     assert not missing, f"guarded kernels not found in the library: {missing}"
     assert not offenders, f"packed fp32 arithmetic in bit-exact kernels: {offenders[:5]} ({len(offenders)} instructions)"
+
+
+# the f16-MFMA-dense kernels themselves (round 4): the split family's records are compared integer for integer with the fp32 oracle, and the K-split
+# A-direct instances exchange fp32 partial accumulators between waves — a f32x4 addition there compiled to v_pk_add_f32
+MFMA_FAMILY = ["conv_split_ad_kernel", "conv_f16_kernel", "conv_f16_ad_kernel", "conv_f16_ws_kernel"]
+
+
+@needs_lib
+def test_no_packed_fp32_arithmetic_anywhere_in_the_library(tmp_path):
+    """Every device function of every gfx950 code object: the library as shipped holds no v_pk_{mul,add,fma}_f32 at all."""
+    seen, offenders = _scan(tmp_path, lambda funcs: funcs)
+    missing = [g for g in MFMA_FAMILY + GUARDED if not any(g in s for s in seen)]
+    assert not missing, f"kernels not found in the library: {missing}"
+    assert len(seen) > 300, f"only {len(seen)} device functions disassembled"
+    by_kernel = sorted({k for k, _ in offenders})
+    assert not offenders, f"packed fp32 arithmetic in {len(by_kernel)} kernels, e.g. {by_kernel[:3]}: {offenders[:3]} ({len(offenders)} instructions)"

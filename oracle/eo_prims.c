@@ -759,12 +759,143 @@ static int eo_get_subset4(const double* src, const double* dst, int n, uint64_t*
 }
 static int eo_cmp_float(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return (x > y) - (x < y); }
 
+/* ---------------------------------------------------------------------------------------------------- */
+/* cv2.RHO (coordinate_model.py:354-357 tries it between cv2.RANSAC and cv2.LMEDS, with the threshold argument None = findHomography's      */
+/* default 3.0).  OpenCV 4.11 modules/calib3d/src/rho.cpp is NOT in /root/reference nor in this image: restated from the publication it        */
+/* implements — Bazargani, Bilaniuk, Laganiere, "A fast and robust homography scheme for real-time planar target detection" (2015):           */
+/* PROSAC sampling (Chum & Matas 2005) over the correspondences in the order given, SPRT verification (Matas & Chum 2005) with the            */
+/* adaptive (epsilon, delta) design, termination by the PROSAC maximality bound / the RANSAC confidence bound, a final refinement over the   */
+/* consensus set.  PARITY UNPINNED.  What is kept from rho.cpp as far as the publication and its defaults define it: sample size 4, SPRT      */
+/* constants t_M = 25, m_S = 1, epsilon0 = 0.1, delta0 = 0.01, re-design when delta moves by more than 10 %, the sample test "no coincident    */
+/* points, no three collinear, same side of the lines (0,1) and (2,3) in both images" (signed distances compared after truncation to int),   */
+/* the model test "no NaN",                                                                                                                  */
+/* acceptance with >= minInl = 4 consensus members, findHomography's arguments (maxIters 2000, confidence 0.995, NR and final refinement     */
+/* enabled, beta 0.35).  Stated deviations: the 4-point model comes from this file's normalised 8 x 8 solver (rho.cpp: float Gauss-Jordan on  */
+/* the un-normalised system), the random stream is cv::RNG's multiply-with-carry (rho.cpp: its own xorshift128+), the refinement is           */
+/* eo_lm_refine (rho.cpp: its own Levenberg-Marquardt with Cholesky steps), no NR-step inside the loop.  None of these changes WHICH inputs  */
+/* yield a model — the question the GPU path depends on (tests/test_oracle_host.py::test_rho_fallback_never_rescues_what_ransac_rejects).     */
+/* ---------------------------------------------------------------------------------------------------- */
+static double eo_sprt_design(double delta, double eps, double tM, double mS)
+{
+    const double C = (1 - delta) * log((1 - delta) / (1 - eps)) + delta * log(delta / eps);
+    const double K = tM * C / mS + 1;
+    double An1 = K, An = K;
+    for (int i = 0; i < 10; ++i) { An = K + log(An1); if (An - An1 < 1.5e-8) break; An1 = An; }
+    return An;
+}
+static int eo_rho_sample_degenerate(const float* src, const float* dst, const int* s)
+{
+    float p[16];
+    for (int k = 0; k < 4; ++k) { p[2 * k] = src[2 * s[k]]; p[2 * k + 1] = src[2 * s[k] + 1]; p[8 + 2 * k] = dst[2 * s[k]]; p[8 + 2 * k + 1] = dst[2 * s[k] + 1]; }
+    for (int a = 0; a < 4; ++a)                               /* two source points that share both coordinates */
+        for (int b = a + 1; b < 4; ++b)
+            if (p[2 * a] == p[2 * b] && p[2 * a + 1] == p[2 * b + 1]) return 1;
+    /* three collinear points in either image: the 8 x 8 system is singular, no homography is determined (the publication's degeneracy test; what
+       rho.cpp's float Gauss-Jordan returns for such a sample is a rounding artefact that this restatement does not imitate) */
+    {
+        const int id[4] = {0, 1, 2, 3};
+        double ps[8], pd[8];
+        for (int k = 0; k < 8; ++k) { ps[k] = p[k]; pd[k] = p[8 + k]; }
+        for (int c = 3; c <= 4; ++c)
+            if (eo_collinear_last(ps, id, c) || eo_collinear_last(pd, id, c)) return 1;
+    }
+    static const int lines[4][3] = {{0, 1, 2}, {0, 1, 3}, {2, 3, 0}, {2, 3, 1}};      /* (line through a, b) . c */
+    for (int t = 0; t < 4; ++t) {
+        const int a = lines[t][0], b = lines[t][1], c = lines[t][2];
+        float d[2];
+        for (int side = 0; side < 2; ++side) {
+            const float* q = p + 8 * side;
+            const float c0 = q[2 * a + 1] - q[2 * b + 1], c1 = q[2 * b] - q[2 * a], c2 = q[2 * a] * q[2 * b + 1] - q[2 * a + 1] * q[2 * b];
+            d[side] = c0 * q[2 * c] + c1 * q[2 * c + 1] + c2;
+        }
+        if ((((int)d[0]) ^ ((int)d[1])) < 0) return 1;        /* opposite sides (the comparison is made on the truncated integers, as rho.cpp does) */
+    }
+    return 0;
+}
+int eo_find_homography_rho(const float* srcf, const float* dstf, int n, double maxD, int maxI, double cfd, int minInl, double* H, uint8_t* mask)
+{
+    if (n < 4) return 0;
+    double* src = (double*)malloc(sizeof(double) * 2 * n);
+    double* dst = (double*)malloc(sizeof(double) * 2 * n);
+    uint8_t* cur = (uint8_t*)malloc(n);
+    for (int i = 0; i < 2 * n; ++i) { src[i] = srcf[i]; dst[i] = dstf[i]; }
+    uint64_t rng = 0xffffffffffffffffULL;
+    const double tM = 25.0, mS = 1.0;
+    double eps = 0.1, delta = 0.01;
+    double A = eo_sprt_design(delta, eps, tM, mS), lamAcc = delta / eps, lamRej = (1 - delta) / (1 - eps);
+    /* PROSAC growth function: T_4 = rConvg * prod (4 - i) / (N - i); phase n draws 3 points from the first n - 1 and takes point n */
+    int phNum = 4, phEndI = 1;
+    double phEndFp = (double)maxI;
+    for (int i = 0; i < 4; ++i) phEndFp *= (double)(4 - i) / (double)(n - i);
+    int best_inl = 0, limit = maxI;
+    double best[9];
+    const float maxD2 = (float)(maxD * maxD);
+    for (int it = 0; it < limit; ++it) {
+        if (it > phEndI && phNum < n) {                       /* next PROSAC phase */
+            ++phNum;
+            const double next = phEndFp * phNum / (phNum - 4);
+            phEndI += (int)ceil(next - phEndFp);
+            phEndFp = next;
+        }
+        int s[4];
+        const int pool = (it > phEndI || phNum >= n) ? n : phNum - 1, m = pool == n ? 4 : 3;
+        for (int i = 0; i < m; ++i) {
+            int v, dup;
+            do { v = (int)(eo_rng_next(&rng) % (uint32_t)pool); dup = 0; for (int j = 0; j < i; ++j) dup |= (s[j] == v); } while (dup);
+            s[i] = v;
+        }
+        if (m == 3) s[3] = phNum - 1;
+        if (eo_rho_sample_degenerate(srcf, dstf, s)) continue;
+        double Hc[9];
+        if (!eo_h4_homography(src, dst, s, Hc)) continue;
+        double sum = 0; for (int k = 0; k < 8; ++k) sum += Hc[k];
+        if (sum != sum) continue;                             /* model test: NaN */
+        /* SPRT: accumulate the likelihood ratio point by point, reject as soon as it passes A */
+        double lam = 1.0; int inl = 0, tested = 0, good = 1;
+        for (int j = 0; j < n; ++j) {
+            const double X = src[2 * j], Y = src[2 * j + 1];
+            const double ww = 1.0 / (Hc[6] * X + Hc[7] * Y + 1.0);
+            const double dx = (Hc[0] * X + Hc[1] * Y + Hc[2]) * ww - dst[2 * j], dy = (Hc[3] * X + Hc[4] * Y + Hc[5]) * ww - dst[2 * j + 1];
+            const int in = (float)(dx * dx + dy * dy) <= maxD2;
+            cur[j] = (uint8_t)in; inl += in; ++tested;
+            lam *= in ? lamAcc : lamRej;
+            if (lam > A) { good = 0; break; }
+        }
+        if (good) {
+            if (inl > best_inl) {
+                best_inl = inl; memcpy(best, Hc, sizeof(best)); memcpy(mask, cur, n);
+                /* termination bounds: RANSAC confidence on the inlier ratio; a larger consensus set also raises epsilon */
+                limit = eo_ransac_update_iters(cfd, (double)(n - inl) / n, 4, limit);
+                const double e2 = (double)inl / n;
+                if (e2 > eps && e2 < 1.0) { eps = e2; if (delta >= eps) delta = eps * 0.5; A = eo_sprt_design(delta, eps, tM, mS); lamAcc = delta / eps; lamRej = (1 - delta) / (1 - eps); }
+            }
+        } else {
+            const double d2 = (double)inl / tested;           /* a rejected model estimates delta */
+            if (d2 > 0 && d2 < eps && fabs(d2 - delta) / delta > 0.1) { delta = d2; A = eo_sprt_design(delta, eps, tM, mS); lamAcc = delta / eps; lamRej = (1 - delta) / (1 - eps); }
+        }
+    }
+    int ok = best_inl >= minInl;
+    if (ok) {
+        if (n > 4) {                                          /* final refinement over the consensus set */
+            double* s2 = (double*)malloc(sizeof(double) * 2 * best_inl); double* d2 = (double*)malloc(sizeof(double) * 2 * best_inl);
+            int k = 0;
+            for (int i = 0; i < n; ++i) if (mask[i]) { s2[2 * k] = src[2 * i]; s2[2 * k + 1] = src[2 * i + 1]; d2[2 * k] = dst[2 * i]; d2[2 * k + 1] = dst[2 * i + 1]; ++k; }
+            eo_lm_refine(s2, d2, k, best, 10);
+            free(s2); free(d2);
+        }
+        memcpy(H, best, sizeof(best));
+    }
+    free(src); free(dst); free(cur);
+    return ok;
+}
+
 /* mode 0: production deviations (8x8 minimal solver, cyclic Jacobi); mode 1: cv2's own solver throughout.
  * method 8 = cv2.RANSAC (thresh used), 4 = cv2.LMEDS (thresh ignored; confidence 0.995, maxIters 2000 as findHomography passes them). */
 int eo_find_homography_ex(const float* srcf, const float* dstf, int n, int method, double thresh, int max_iters,
                           double confidence, int refine_iters, int mode, double* H, uint8_t* mask)
 {
     if (n < 4) return 0;
+    if (method == 16) return eo_find_homography_rho(srcf, dstf, n, thresh, max_iters, confidence, 4, H, mask);      /* cv2.RHO */
     if (method == 8 && mode == 0) return eo_find_homography_ransac(srcf, dstf, n, thresh, max_iters, confidence, refine_iters, H, mask);
     double* src = (double*)malloc(sizeof(double) * 2 * n);
     double* dst = (double*)malloc(sizeof(double) * 2 * n);

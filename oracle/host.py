@@ -271,7 +271,9 @@ def solve_homography(keypoints):
         return None, keypoints
     H, mask = P.find_homography_ransac(img_pts, world_pts, 5.0)          # cm.py:354-357: cv2.RANSAC ...
     if H is None:
-        H, mask = P.find_homography(img_pts, world_pts, 4)               # ... (cv2.RHO not restated: "no model") ... cv2.LMEDS
+        H, mask = P.find_homography(img_pts, world_pts, 16, 3.0)         # ... cv2.RHO (threshold None = the default 3.0; restated, parity unpinned) ...
+    if H is None:
+        H, mask = P.find_homography(img_pts, world_pts, 4)               # ... cv2.LMEDS
     if H is None:
         return None, keypoints
     kept = {k: v for k, v, m in zip(used, img_pts.tolist(), mask.flatten()) if m}

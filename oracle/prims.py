@@ -143,7 +143,7 @@ def dlt_homography(src, dst):
 
 
 def find_homography(src, dst, method=8, thresh=5.0, max_iters=2000, confidence=0.995, refine_iters=10, cv_solver=False):
-    """cv2.findHomography(src, dst, method, thresh): method 8 = cv2.RANSAC, 4 = cv2.LMEDS.  cv_solver=True: OpenCV's own minimal solver
+    """cv2.findHomography(src, dst, method, thresh): method 8 = cv2.RANSAC, 16 = cv2.RHO (PROSAC + SPRT, eo_find_homography_rho), 4 = cv2.LMEDS.  cv_solver=True: OpenCV's own minimal solver
     and Jacobi (the second CPU mode of eo_prims.c) instead of the production deviations.  -> (H float64 3x3, mask uint8 [n,1]) | (None, None)"""
     src = _f32(src).reshape(-1, 2); dst = _f32(dst).reshape(-1, 2)
     n = src.shape[0]

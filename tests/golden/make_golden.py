@@ -88,10 +88,12 @@ def install_stubs():
         *P.calc_optical_flow_pyr_lk(prev, cur, pts, maxLevel, criteria[1], criteria[2]), None)
 
     def find_h(src, dst, method, thr=None):
-        # cm.py:354-357 tries cv2.RANSAC (8), cv2.RHO (16), cv2.LMEDS (4) in turn.  RANSAC and LMEDS are served by the oracle's
-        # restatements; RHO (PROSAC + SPRT, not restated) reports "no model", which hands over to LMEDS like a failed RHO does.
+        # cm.py:354-357 tries cv2.RANSAC (8), cv2.RHO (16), cv2.LMEDS (4) in turn: all three are served by the oracle's restatements
+        # (a threshold of None is findHomography's default 3.0; LMEDS ignores it)
         if method == 8:
             H, mask = P.find_homography(src, dst, 8, 5.0 if thr is None else thr)
+        elif method == 16:
+            H, mask = P.find_homography(src, dst, 16, 3.0 if thr is None else thr)
         elif method == 4:
             H, mask = P.find_homography(src, dst, 4)
         else:

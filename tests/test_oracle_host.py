@@ -237,3 +237,50 @@ def test_lmeds_fallback_never_rescues_what_ransac_rejects():
         err = np.linalg.norm(pts[:, :2] / pts[:, 2:] - world, axis=1)
         close += np.median(err[ml.ravel() > 0]) < 2.0
     assert close >= 95, close
+
+
+def test_rho_fallback_never_rescues_what_ransac_rejects():
+    """cv2.RHO sits between RANSAC and LMEDS in cm.py:354-357.  Restated in oracle/eo_prims.c::eo_find_homography_rho (PROSAC + SPRT from the
+    publication, parity unpinned).  The GPU kernel runs "RANSAC or nothing": that is the reference's loop iff RHO never returns a model where
+    RANSAC returned none.  RANSAC (>= 5 points) returns none only when no admissible 4-subset exists (exactly collinear triples / duplicates in
+    every subset, or inconsistent orientation everywhere); on those inputs every 4-point model RHO can form is singular or has no consensus of
+    4 within 3 m, so it reports none too.  Degenerate families as in the LMEDS test plus reflected correspondences; on ordinary inputs RHO's H
+    is close to RANSAC's (so the restatement is not vacuous)."""
+    from oracle import prims as P
+    rng = np.random.default_rng(11)
+    rescued = degenerate = 0
+    for _ in range(400):
+        n = int(rng.integers(5, 30))
+        kind = rng.integers(0, 4)
+        t = rng.integers(0, 60, n).astype(np.float64)
+        if kind == 0:        # all image points EXACTLY on one line (integer multiples of an integer direction)
+            img = np.stack([100 + 9 * t, 50 + 4 * t], 1)
+        elif kind == 1:      # all but one on a line
+            img = np.stack([100 + 9 * t, 50 + 4 * t], 1); img[0] = (700, 90)
+        elif kind == 2:      # two coincident clusters
+            img = np.where(rng.random((n, 1)) < 0.5, np.array([[200., 200.]]), np.array([[800., 500.]]))
+        else:                # all world points on one line (a touch-line): image points in general position
+            img = np.stack([rng.uniform(0, 1280, n), rng.uniform(0, 720, n)], 1)
+        world = np.stack([rng.uniform(0, 105, n), rng.uniform(0, 68, n)], 1)
+        if kind == 3:
+            world[:, 1] = 0.0
+        Hr, _ = P.find_homography(np.floor(img), world, 8, 5.0)
+        if Hr is None:
+            degenerate += 1
+            Hq, _ = P.find_homography(np.floor(img), world, 16, 3.0)
+            rescued += Hq is not None
+    assert degenerate > 100 and rescued == 0, (degenerate, rescued)
+    close = found = 0
+    for _ in range(100):
+        img, world = _random_h_case(rng)
+        Hr, mr = P.find_homography(img, world, 8, 5.0)
+        Hq, mq = P.find_homography(img, world, 16, 3.0)
+        assert Hr is not None
+        if Hq is None:
+            continue
+        found += 1
+        assert mq.sum() >= 4
+        pts = np.c_[img, np.ones(len(img))] @ Hq.T
+        err = np.linalg.norm(pts[:, :2] / pts[:, 2:] - world, axis=1)
+        close += np.median(err[mq.ravel() > 0]) < 2.0
+    assert found >= 95 and close >= 0.95 * found, (found, close)

@@ -132,17 +132,25 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
     c.wx = (wo > 16) ? 2 : 1;
     static const int nts[] = {6, 4, 3, 2, 1};
     if (precision == EAGLE_PREC_F32) {
+        if (const char* f = getenv("EAGLE_F32_FORCE")) {    // "nt,wx,variant": parity tests of the tilings (every tiling gives the same bits)
+            ConvConfig q = c; q.kc = (cin_pad < 16) ? 4 : 16;
+            if (sscanf(f, "%d,%d,%d", &q.nt, &q.wx, &q.variant) == 3 && cout_pad % (16 * q.nt) == 0 && find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
+        }
         static const bool tuned32 = !(getenv("EAGLE_CONV_TUNED") && atoi(getenv("EAGLE_CONV_TUNED")) == 0);
         if (tuned32)
             for (const Tuned& t : g_tuned_f32)
                 if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
-                    ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = 0;
+                    ConvConfig q = c; q.kc = t.kc; q.nt = t.nt; q.wx = t.wx; q.variant = t.variant;      // variant: 0 full, 3 half, 4 quarter tiles
                     if (find_inst(precision, q)) return q;
                 }
         c.nt = 1;
         for (int nt : nts)
             if (cout_pad % (16 * nt) == 0) { c.nt = nt; break; }
         c.kc = (cin_pad < 16) ? 4 : 16;
+        if (stride == 2 && ks == 3) {                       // the halo of a stride-2 tile is four times the tile: half tiles keep two workgroups on a CU
+            ConvConfig q = c; q.variant = 3;
+            if (find_inst(precision, q)) return q;
+        }
         return c;
     }
     if (precision == EAGLE_PREC_F32S) {
@@ -420,7 +428,15 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     const int th = 4 * conv_pw(c) / c.wx, tw = 16 * c.wx;
     a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
     a.nchunks = c.cin / c.kc;
-    a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1;
+    a.zeros = conv_zero_page(); a.trash = conv_trash_page(); a.xcd = 0; a.gy = 1; a.stack = 0;
+    if (precision == EAGLE_PREC_F32) {
+        // row stacking (conv_f32_kernel): stride-1 layers of a batch are tiled as one image of N (Ho + 1) rows
+        const char* se = getenv("EAGLE_F32_STACK");          // (read per launch: the parity test switches it)
+        const bool stack_on = !(se && atoi(se) == 0);
+        if (stack_on && c.stride == 1 && a.N > 1 && a.Ho == a.H) { a.stack = 1; a.tiles_y = (a.N * (a.Ho + 1) + th - 1) / th; }
+        // raw buffer descriptors with 32-bit byte offsets for the activation loads
+        if ((size_t)a.N * a.H * a.W * a.xcs * 4 >= ((size_t)1 << 31)) fail(EAGLE_E_INVALID, "fp32 conv: the input tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
+    }
     a.am = L.am_slot ? *L.am_slot : nullptr; a.am_cs = c.cout_pad;
     a.sat = (L.sat_slot && precision == EAGLE_PREC_F32S) ? *L.sat_slot : nullptr;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
@@ -457,7 +473,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     const size_t lds = lds_bytes(precision, c);
     ensure_max_dynamic_lds((const void*)inst->fn, 160 * 1024);
     const int gy = c.cout_pad / (c.nt * 16);
-    int gx = a.tiles_x * a.tiles_y * a.N;
+    int gx = a.stack ? a.tiles_x * a.tiles_y : a.tiles_x * a.tiles_y * a.N;
     if (conv_ws(c)) {                                       // persistent, weight-stationary: 8*gy | grid, as many workgroups as stay resident
         if (c.kc != c.cin || a.out_f32 || a.r2 || a.pre_act != 0 || a.post_act > 1 || (size_t)a.N * a.H * a.W * a.xcs * 2 >= (1ull << 31) || (size_t)a.N * a.Ho * a.Wo * std::max(a.ycs, a.r1 ? a.r1cs : 0) * 2 >= (1ull << 31))
             fail(EAGLE_E_NOKERNEL, "weight-stationary conv needs kc == cin, fp16 output, at most one residual, pre_act none, post_act in {none, ReLU} and tensors below 2 GiB (kc=%d cin=%d)", c.kc, c.cin);

@@ -20,6 +20,7 @@ struct ConvArgs {
     int pre_act, post_act, out_f32;
     int wx, tiles_x, tiles_y, nchunks;
     int gy;                 // number of Cout blocks
+    int stack;              // EAGLE_PREC_F32, stride 1: the batch tiled as one image of N (H + 1) rows (conv_f32_kernel); tiles_y then counts the whole batch
     int xcd;                // 1: XCD-aware work order (1-D grid; each XCD owns a contiguous range of (tile, Cout-block) items)
     ArgmaxPart* am;         // fused heat-map maxima (head convolution): partials [frame][tile][am_cs] instead of the output tensor
     int am_cs;

@@ -72,6 +72,31 @@ def test_conv_parity(case, prec):
         assert err < F16_TOL, f"fp16 conv error {err}"
 
 
+@pytest.mark.parametrize("stack", ["1", "0"])
+@pytest.mark.parametrize("force", ["3,2,0", "3,1,0", "6,2,3", "3,1,3", "2,2,4", "1,1,4"])
+@pytest.mark.parametrize("shape,ks,st,cin,cout", [((5, 17, 30), 3, 1, 48, 96), ((4, 7, 45), 3, 1, 32, 48), ((3, 34, 61), 3, 2, 48, 96), ((6, 12, 20), 1, 1, 64, 96),
+                                                  ((7, 1, 1), 3, 1, 16, 48), ((2, 33, 37), 3, 2, 3, 48)])
+def test_conv_f32_every_tiling_is_bit_exact(shape, ks, st, cin, cout, force, stack, monkeypatch):
+    """The exact family's tilings (round 4): full / half / quarter tiles (variants 0 / 3 / 4), 16 x 16 or 8 x 32 sub-tile arrangement, and the
+    batch tiled as ONE image of N (H + 1) rows for stride-1 layers (a tile may straddle several frames; the virtual zero row between two
+    frames is both frames' padding).  The K order of every output is the canonical one whatever the tiling: bit-equal to the oracle, with
+    residual and ReLU, on maps whose rows do not divide the tile (17, 7, 1) and batches of 2 - 7 frames."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    monkeypatch.setenv("EAGLE_F32_FORCE", force)
+    monkeypatch.setenv("EAGLE_F32_STACK", stack)
+    n, h, w = shape
+    x = _rand((n, h, w, cin), 61)
+    wt = _rand((ks, ks, cin, cout), 62, (2.0 / (cin * ks * ks)) ** 0.5)
+    b = _rand((cout,), 63, 0.1)
+    ho = (h + 2 * (ks // 2) - ks) // st + 1
+    wo = (w + 2 * (ks // 2) - ks) // st + 1
+    r1 = _rand((n, ho, wo, cout), 64)
+    ref = P.conv2d(x, wt, b, stride=st, pre=0, r1=r1, r2=None, post=1)
+    got = lib.op_conv2d(x, wt, b, st, 0, r1, None, 1, lib.PREC_F32)
+    assert np.array_equal(ref, got), f"fp32 conv tiling {force} stack {stack} not bit-exact: max|d|={np.abs(ref - got).max()}"
+
+
 @pytest.mark.parametrize("force,cin,cout", [("48,3,6", 48, 48), ("48,3,7", 48, 48), ("96,3,7", 96, 96), ("96,3,6", 96, 96),
                                             ("64,4,7", 64, 64), ("96,2,7", 96, 32)])
 @pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16)])

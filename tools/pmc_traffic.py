@@ -21,7 +21,10 @@ out = {"build": "libeagle_hip.so md5 " + hashlib.md5(open(_lib, "rb").read()).he
        "corrections": "bytes = KiB*1024; FETCH_SIZE doubled (gfx950 under-report of wide coalesced reads)", "kernels": {}}
 tf = tw = n = 0
 for k in fetch:
-    if "conv_f16" not in k and "conv_f32_kernel" not in k and "conv_split" not in k:
+    # the convolution family of the KEY-POINT network's precision (the default handle runs its detector in the exact fp32 family: those
+    # conv_f32_kernel launches belong to `detector_convs`, not to the roofline family)
+    fam = ("conv_f32_kernel",) if out["precision"] == "f32" else ("conv_f16", "conv_split")
+    if not any(t in k for t in fam):
         continue
     c, v = fetch[k]
     w = write.get(k, [c, 0.0])[1]

@@ -22,118 +22,7 @@ namespace eagle {
 #define RNG_N 65536        // precomputed draws of cv::RNG(-1): the stream does not depend on the data
 #define DEPS 2.220446049250313e-16
 
-// ---- 9x9 symmetric eigen-solve: classic cyclic Jacobi on the upper triangle, eigenvector of the smallest
-// eigenvalue.  Same operations in the same order as oracle/eo_prims.c::eo_jacobi9_smallest.  Every index below is a
-// compile-time constant after unrolling, so a[][], V[][], d, b, z live in registers (no scratch).
 #define JROT(x, y) do { const double g_ = (x), h_ = (y); (x) = g_ - s * (h_ + g_ * tau); (y) = h_ + s * (g_ - h_ * tau); } while (0)
-__device__ __forceinline__ void jacobi9_smallest(double (&a)[9][9], double (&v)[9])
-{
-    double V[9][9], d[9], b[9], z[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-        d[i] = b[i] = a[i][i]; z[i] = 0.0;
-    }
-    for (int sweep = 1; sweep <= 50; ++sweep) {
-        double sm = 0.0;
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 9; ++q) sm += fabs(a[p][q]);
-        if (sm == 0.0) break;
-        const double tresh = sweep < 4 ? 0.2 * sm / 81.0 : 0.0;
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 9; ++q) {
-                const double g = 100.0 * fabs(a[p][q]);
-                if (sweep > 4 && fabs(d[p]) + g == fabs(d[p]) && fabs(d[q]) + g == fabs(d[q])) {
-                    a[p][q] = 0.0;
-                } else if (fabs(a[p][q]) > tresh) {
-                    double h = d[q] - d[p], t;
-                    if (fabs(h) + g == fabs(h)) {
-                        t = a[p][q] / h;
-                    } else {
-                        const double theta = 0.5 * h / a[p][q];
-                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
-                        if (theta < 0.0) t = -t;
-                    }
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c);
-                    h = t * a[p][q];
-                    z[p] -= h; z[q] += h; d[p] -= h; d[q] += h; a[p][q] = 0.0;
-#pragma unroll
-                    for (int j = 0; j < p; ++j) JROT(a[j][p], a[j][q]);
-#pragma unroll
-                    for (int j = p + 1; j < q; ++j) JROT(a[p][j], a[j][q]);
-#pragma unroll
-                    for (int j = q + 1; j < 9; ++j) JROT(a[p][j], a[q][j]);
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) JROT(V[j][p], V[j][q]);
-                }
-            }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { b[i] += z[i]; d[i] = b[i]; z[i] = 0.0; }
-    }
-    int m = 0;
-    double dm = d[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) if (d[i] < dm) { dm = d[i]; m = i; }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        double r = V[k][0];
-#pragma unroll
-        for (int i = 1; i < 9; ++i) r = (m == i) ? V[k][i] : r;
-        v[k] = r;
-    }
-}
-
-// ---- normalised DLT ("runKernel") ---------------------------------------------------------------------------
-__device__ __noinline__ int dlt_homography(const double* src, const double* dst, const int* sel, int n, double* H)
-{
-    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
-    for (int i = 0; i < n; ++i) {
-        const int k = sel ? sel[i] : i;
-        cM[0] += src[2 * k]; cM[1] += src[2 * k + 1]; cm[0] += dst[2 * k]; cm[1] += dst[2 * k + 1];
-    }
-    cM[0] /= n; cM[1] /= n; cm[0] /= n; cm[1] /= n;
-    for (int i = 0; i < n; ++i) {
-        const int k = sel ? sel[i] : i;
-        sM[0] += fabs(src[2 * k] - cM[0]); sM[1] += fabs(src[2 * k + 1] - cM[1]);
-        sm[0] += fabs(dst[2 * k] - cm[0]); sm[1] += fabs(dst[2 * k + 1] - cm[1]);
-    }
-    if (fabs(sM[0]) < DEPS || fabs(sM[1]) < DEPS || fabs(sm[0]) < DEPS || fabs(sm[1]) < DEPS) return 0;
-    sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
-    double LtL[9][9];
-#pragma unroll
-    for (int a = 0; a < 9; ++a)
-#pragma unroll
-        for (int b = 0; b < 9; ++b) LtL[a][b] = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const int k = sel ? sel[i] : i;
-        const double X = (src[2 * k] - cM[0]) * sM[0], Y = (src[2 * k + 1] - cM[1]) * sM[1];
-        const double x = (dst[2 * k] - cm[0]) * sm[0], y = (dst[2 * k + 1] - cm[1]) * sm[1];
-        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-#pragma unroll
-        for (int a = 0; a < 9; ++a)
-#pragma unroll
-            for (int b = a; b < 9; ++b) LtL[a][b] += Lx[a] * Lx[b] + Ly[a] * Ly[b];
-    }
-    double h[9];
-    jacobi9_smallest(LtL, h);
-    const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
-    const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
-    double t[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += iT[3 * r + k] * h[3 * k + c]; t[3 * r + c] = s; }
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += t[3 * r + k] * T[3 * k + c]; H[3 * r + c] = s; }
-    if (fabs(H[8]) < DEPS) return 0;
-    const double inv = 1.0 / H[8];
-    for (int k = 0; k < 9; ++k) H[k] *= inv;
-    H[8] = 1.0;
-    return 1;
-}
-
 __device__ __forceinline__ float reproj_err1(const double* src, const double* dst, int i, const double* H)
 {
     const double X = src[2 * i], Y = src[2 * i + 1];
@@ -314,6 +203,8 @@ struct HomoShared {
     double s2[2 * EAGLE_MAX_KP], d2[2 * EAGLE_MAX_KP];
     double cand[POST_T][9];
     double best[9];
+    double jA[9][9], jV[9][9], jd[9], jb[9], jz[9], jH[9];      // the all-inlier fit: 9 x 9 LtL (upper triangle), eigenvectors, Jacobi vectors, result
+    int jok;
     double lm_r[2 * EAGLE_MAX_KP], lm_rn[2 * EAGLE_MAX_KP], lm_J[16 * EAGLE_MAX_KP];
     double lm_A[8][8], lm_g[8], lm_h[8], lm_hn[8];
     double lm_S;
@@ -329,6 +220,113 @@ struct HomoShared {
     unsigned char len[RANSAC_WIN];     // draws it consumes (0 = stream exhausted)
     int start[POST_T];
 };
+
+// ---- normalised DLT ("runKernel") of n points + 9 x 9 symmetric eigen-solve (classic cyclic Jacobi on the upper triangle, eigenvector of the
+// smallest eigenvalue), by the whole workgroup.  Same operations in the same order PER VALUE as oracle/eo_prims.c::eo_dlt_homography /
+// eo_jacobi9_smallest, so H stays bit-identical: every LtL entry is its own sequential sum over the points (one lane per entry); a Jacobi rotation's
+// parameters are computed redundantly by every thread from the same LDS values (uniform control flow), and its element updates — each touches only
+// its own pair of entries — are spread over lanes.  Until round 4 one lane ran all of it with the matrices in registers: 306 live doubles, i.e. the
+// 941 scratch instructions of this file; now the matrices live in LDS and the kernel has no scratch.
+// All threads call; barriers inside; result in S.jH, returns S.jok (uniform).
+__device__ int dlt_homography_block(HomoShared& S, const double* src, const double* dst, int n)
+{
+    const int tid = threadIdx.x;
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};      // redundantly in every thread (n <= 87)
+    for (int i = 0; i < n; ++i) { cM[0] += src[2 * i]; cM[1] += src[2 * i + 1]; cm[0] += dst[2 * i]; cm[1] += dst[2 * i + 1]; }
+    cM[0] /= n; cM[1] /= n; cm[0] /= n; cm[1] /= n;
+    for (int i = 0; i < n; ++i) {
+        sM[0] += fabs(src[2 * i] - cM[0]); sM[1] += fabs(src[2 * i + 1] - cM[1]);
+        sm[0] += fabs(dst[2 * i] - cm[0]); sm[1] += fabs(dst[2 * i + 1] - cm[1]);
+    }
+    if (fabs(sM[0]) < DEPS || fabs(sM[1]) < DEPS || fabs(sm[0]) < DEPS || fabs(sm[1]) < DEPS) return 0;      // uniform
+    sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
+    __syncthreads();                                       // (the previous user of S.jA / S.jV is done)
+    if (tid < 81) {
+        const int a = tid / 9, b = tid - a * 9;
+        double acc = 0.0;
+        if (b >= a) {                                      // entry (a, b) of the upper triangle: its own sum over the points, in point order
+            for (int i = 0; i < n; ++i) {
+                const double X = (src[2 * i] - cM[0]) * sM[0], Y = (src[2 * i + 1] - cM[1]) * sM[1];
+                const double x = (dst[2 * i] - cm[0]) * sm[0], y = (dst[2 * i + 1] - cm[1]) * sm[1];
+                const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+                const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+                double lxa = Lx[0], lxb = Lx[0], lya = Ly[0], lyb = Ly[0];
+#pragma unroll
+                for (int k = 1; k < 9; ++k) { lxa = (a == k) ? Lx[k] : lxa; lxb = (b == k) ? Lx[k] : lxb; lya = (a == k) ? Ly[k] : lya; lyb = (b == k) ? Ly[k] : lyb; }
+                acc += lxa * lxb + lya * lyb;
+            }
+        }
+        S.jA[a][b] = acc;
+        S.jV[a][b] = (a == b) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (tid < 9) { S.jd[tid] = S.jb[tid] = S.jA[tid][tid]; S.jz[tid] = 0.0; }
+    __syncthreads();
+    for (int sweep = 1; sweep <= 50; ++sweep) {
+        double smm = 0.0;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) smm += fabs(S.jA[p][q]);
+        if (smm == 0.0) break;
+        const double tresh = sweep < 4 ? 0.2 * smm / 81.0 : 0.0;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = S.jA[p][q], dp = S.jd[p], dq = S.jd[q];
+                const double g = 100.0 * fabs(apq);
+                if (sweep > 4 && fabs(dp) + g == fabs(dp) && fabs(dq) + g == fabs(dq)) {
+                    __syncthreads();                       // every thread has read a[p][q]
+                    if (tid == 0) S.jA[p][q] = 0.0;
+                    __syncthreads();
+                } else if (fabs(apq) > tresh) {
+                    double h = dq - dp, t;
+                    if (fabs(h) + g == fabs(h)) {
+                        t = apq / h;
+                    } else {
+                        const double theta = 0.5 * h / apq;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c);
+                    h = t * apq;
+                    __syncthreads();                       // every thread has read a[p][q], d[p], d[q]
+                    if (tid == 0) {
+                        S.jz[p] -= h; S.jz[q] += h; S.jd[p] -= h; S.jd[q] += h; S.jA[p][q] = 0.0;
+                    } else if (tid >= 1 && tid <= 9) {     // the rotation on the other entries of rows / columns p, q of the upper triangle
+                        const int j = tid - 1;
+                        if (j < p) JROT(S.jA[j][p], S.jA[j][q]);
+                        else if (j > p && j < q) JROT(S.jA[p][j], S.jA[j][q]);
+                        else if (j > q) JROT(S.jA[p][j], S.jA[q][j]);
+                    } else if (tid >= 16 && tid < 25) {    // and on the eigenvector columns
+                        const int j = tid - 16;
+                        JROT(S.jV[j][p], S.jV[j][q]);
+                    }
+                    __syncthreads();
+                }
+            }
+        if (tid < 9) { S.jb[tid] += S.jz[tid]; S.jd[tid] = S.jb[tid]; S.jz[tid] = 0.0; }
+        __syncthreads();
+    }
+    int m = 0;
+    double dm = S.jd[0];
+    for (int i = 1; i < 9; ++i) if (S.jd[i] < dm) { dm = S.jd[i]; m = i; }
+    double hv[9];
+    for (int k = 0; k < 9; ++k) hv[k] = S.jV[k][m];
+    const double iT[9] = {1.0 / sm[0], 0, cm[0], 0, 1.0 / sm[1], cm[1], 0, 0, 1};
+    const double T[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double t3[9], Hh[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double sacc = 0; for (int k = 0; k < 3; ++k) sacc += iT[3 * r + k] * hv[3 * k + c]; t3[3 * r + c] = sacc; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double sacc = 0; for (int k = 0; k < 3; ++k) sacc += t3[3 * r + k] * T[3 * k + c]; Hh[3 * r + c] = sacc; }
+    int ok = 1;
+    if (fabs(Hh[8]) < DEPS) ok = 0;
+    if (ok) {
+        const double inv = 1.0 / Hh[8];
+        for (int k = 0; k < 9; ++k) Hh[k] *= inv;
+        Hh[8] = 1.0;
+    }
+    __syncthreads();                                       // every thread has read S.jV / S.jd
+    if (tid == 0) { for (int k = 0; k < 9; ++k) S.jH[k] = Hh[k]; S.jok = ok; }
+    __syncthreads();
+    return ok;
+}
 
 // refine S.best over the ni inlier points in S.s2/S.d2 (all threads call; barriers inside)
 __device__ void lm_refine_block(HomoShared& S, int n, int max_iters)
@@ -404,10 +402,10 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
     __syncthreads();
     if (n < 4) return;
     if (n == 4) {
+        const int ok4 = dlt_homography_block(S, S.src, S.dst, 4);
         if (tid == 0) {
-            double Hc[9];
-            S.ok = dlt_homography(S.src, S.dst, nullptr, 4, Hc);
-            for (int k = 0; k < 9; ++k) S.best[k] = Hc[k];
+            S.ok = ok4;
+            for (int k = 0; k < 9; ++k) S.best[k] = S.jH[k];
             for (int i = 0; i < n; ++i) S.mask[i] = 1;
         }
         __syncthreads();
@@ -564,13 +562,17 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
         int ni = 0;
         for (int i = 0; i < n; ++i)
             if (S.mask[i]) { S.s2[2 * ni] = S.src[2 * i]; S.s2[2 * ni + 1] = S.src[2 * i + 1]; S.d2[2 * ni] = S.dst[2 * i]; S.d2[2 * ni + 1] = S.dst[2 * i + 1]; ++ni; }
-        double Hr[9];
-        S.ni = 0;
-        if (dlt_homography(S.s2, S.d2, nullptr, ni, Hr)) {
-            for (int k = 0; k < 9; ++k) S.best[k] = Hr[k];
-            S.ni = ni;
-        }
+        S.ni = ni;
         S.ok = 1;
+    }
+    __syncthreads();
+    {
+        const int ni = S.ni;                               // (uniform)
+        const int okf = dlt_homography_block(S, S.s2, S.d2, ni);
+        if (tid == 0) {
+            if (okf) { for (int k = 0; k < 9; ++k) S.best[k] = S.jH[k]; }
+            else S.ni = 0;
+        }
     }
     __syncthreads();
     if (S.ni > 0 && lm_iters > 0) lm_refine_block(S, S.ni, lm_iters);

@@ -258,6 +258,33 @@ def test_bench_multirank_process_composition_with_nccl_group_and_library_rccl(ga
     assert "bootstrap failed" not in r.stderr, r.stderr[-3000:]
 
 
+def test_bench_default_line_carries_the_measurement_contract():
+    """`python bench.py` at N = 1 (small sizes): ONE JSON line with the contract's fields — value from host frames, `roofline` with frac = achieved / peak and
+    the dominant kernel named, `cpu_baseline` from the child process, `parity_counters.default` all zero, `saturation` 0 / 0 — and the process never imported
+    torch (the child did)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--distinct", "4", "--cpu-frames", "1",
+                        "--exact-frames", "8", "--fast-frames", "8", "--cfg3-frames", "0"], capture_output=True, text=True, timeout=900, cwd=root,
+                       env=dict(os.environ, OMP_NUM_THREADS="8"))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["input"].startswith("pageable host memory") and d["config"]["detector_precision"] == "f32" and d["config"]["keypoint_precision"] == "f32s"
+    assert abs(d["value"] - d["host_sources"]["pageable"]) < 1e-6 and d["resident"]["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["dominant_kernel"]["avg_us"] > 0 and 0 < rf["dominant_kernel"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    pc = d["parity_counters"][d["parity_counters"]["default"]]
+    assert all(pc[k] == 0 for k in ("hm_idx", "n_kp", "kp_pixels", "n_det", "det_cls", "det_int_box", "det_pitch_int", "det_id", "H_valid", "det_unmatched")) and pc["dets_compared"] > 0
+    assert d["saturation"]["sat_events"] == 0 and d["saturation"]["sat_frames"] == 0
+    assert d["detector_convs"]["family"] == "f32" and d["exact_family"]["value"] > 0 and d["fast_family"]["value"] > 0 and d["split_detector"]["value"] > 0
+
+
 def test_torch_after_the_first_handle_is_refused():
     """eagle_amd.lib.require_torch_first: the code paths of the package that import torch refuse to do so once a handle exists in a process
     that has not imported torch yet (the order that maps two ROCm runtimes)."""

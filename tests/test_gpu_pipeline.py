@@ -701,6 +701,40 @@ def test_f32s_full_size_clip_properties(state_dicts):
     assert ra[:148].tobytes() == rb.tobytes() == rb2.tobytes()
 
 
+def test_cfg3_full_size_clip_properties():
+    """BASELINE.json's configs[2] at full size through the DEFAULT handle (1000 frames of 1920x1080, yolov8l@960 in the exact family + HRNet in the
+    split family, device batch 25 — the bench's cfg3 run): every copy of a frame yields byte-identical records wherever it sits in the clip and in its
+    batch, a different device batch (13: ragged last batch) yields the same records, the host-fed path equals the resident path, no frame reports a
+    clipped activation, and the records are sane (detections in descending confidence, ids by the detection-index rule)."""
+    from eagle_amd import synth, weights
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, yl = weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("l", 0)
+    base = np.stack([synth.frame(0, t, 1080, 1920) for t in range(10)])
+    clip = np.ascontiguousarray(np.tile(base, (100, 1, 1, 1)))
+    a = CoordinateModel(batch=25, frame_hw=(1080, 1920), detector="l", det_imgsz=960, hrnet_state_dict=hs, detector_state_dict=yl)
+    ra = a.process_records(clip)                                  # host frames: eagle_process_frames
+    d = a.handle.upload(clip)
+    rd = np.zeros(len(clip), ra.dtype)
+    a.handle.process_device(d, len(clip), rd)                     # resident frames: eagle_process_device_frames
+    a.handle.free(d)
+    t = a.handle.timings()
+    a.handle.close()
+    assert ra.tobytes() == rd.tobytes()
+    assert (t.sat_events, t.sat_frames) == (0, 0) and not ra["pad"][:, 1].any()
+    for k in range(10):
+        first = ra[k].tobytes()
+        assert all(ra[j].tobytes() == first for j in range(k, 1000, 10)), k
+    for r in ra[:10]:
+        n = int(r["n_det"])
+        assert n > 0 and np.all(np.diff(r["det"]["conf"][:n]) <= 0)
+        persons = np.isin(r["det"]["cls"][:n], (0, 1))
+        assert np.array_equal(r["det"]["id"][:n][persons], np.nonzero(persons)[0])
+    b = CoordinateModel(batch=13, frame_hw=(1080, 1920), detector="l", det_imgsz=960, hrnet_state_dict=hs, detector_state_dict=yl)
+    rb = b.process_records(clip[:100])
+    b.handle.close()
+    assert ra[:100].tobytes() == rb.tobytes()
+
+
 def test_f32s_batch_and_position_invariance(state_dicts, frames):
     from eagle_amd.coordinate_model import CoordinateModel
     hs, ys = state_dicts

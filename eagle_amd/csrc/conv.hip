@@ -32,10 +32,10 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : c.variant == 4 ? 1 : c.variant == 18 ? 6 : 4; }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
-static bool conv_ad(const ConvConfig& c) { return c.variant >= 8 && c.variant <= 15; }
+static bool conv_ad(const ConvConfig& c) { return (c.variant >= 8 && c.variant <= 15) || c.variant == 19; }
 static bool conv_ad_s2t(const ConvConfig& c) { return c.variant == 14 || c.variant == 15; }      // TRUE stride 2 on a column-plane halo (14: BN 192; 15: BN 96, K split over wave pairs)
 static bool conv_ad_s2d(const ConvConfig& c) { return c.variant == 10 || c.variant == 11; }      // stride 2 over the space-to-depth image (variants 14 / 15: true stride 2, the stride-1 weight image)
-static int conv_ad_rows(const ConvConfig& c) { return (c.variant == 8 || c.variant == 10 || conv_ad_s2t(c)) ? 4 : c.variant == 13 ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
+static int conv_ad_rows(const ConvConfig& c) { return (c.variant == 8 || c.variant == 10 || conv_ad_s2t(c)) ? 4 : (c.variant == 13 || c.variant == 19) ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
 static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10 || c.variant == 14; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
@@ -84,6 +84,8 @@ static const Inst g_ad_inst[] = {
     {EAGLE_PREC_F32S, 3, 1, 16, 3, 12, nullptr},
     // the same Cout with four pixel groups (16 x 32 tile) and a single halo buffer (variant 13)
     {EAGLE_PREC_F32S, 3, 1, 16, 3, 13, nullptr},
+    // ... and with the two-deep halo ring: 130 KB of LDS, ONE persistent workgroup per CU whose ring runs on across its items (variant 19, round 4)
+    {EAGLE_PREC_F32S, 3, 1, 16, 3, 19, nullptr},
     // split family, stride 2 over the space-to-depth image (variants 10 / 11)
     {EAGLE_PREC_F32S, 3, 2, 16, 12, 10, nullptr}, {EAGLE_PREC_F32S, 3, 2, 16, 6, 11, nullptr},
     // split family, TRUE stride 2 on an even / odd column-plane halo, the stride-1 weight image (variant 14: BN = 192, tile 4 x 32, one halo buffer)
@@ -169,7 +171,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         //  21 K-steps per wave, too little work against the exchange, the epilogue and three barriers; kept for the tuner, off by default)
         const bool kq_on = getenv("EAGLE_CONV_KQ") && atoi(getenv("EAGLE_CONV_KQ")) != 0;      // (read per call: the parity test switches it on)
         if (sad_on && kq_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 48 == 0 && cout_pad % 96 != 0) {      // Cout = 48 (144, ...): K split over wave pairs
-            ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = atoi(getenv("EAGLE_CONV_KQ")) == 13 ? 13 : 12;
+            ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = atoi(getenv("EAGLE_CONV_KQ")) == 13 ? 13 : atoi(getenv("EAGLE_CONV_KQ")) == 19 ? 19 : 12;
             return q;
         }
         // 3x3 stride 2 with Cin = 48 k, Cout = 96 k (HRNet's transition / fuse down-sampling chains): the TRUE stride-2 A-direct forms.  Same box, all
@@ -451,14 +453,15 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 19) ? conv_ad_split_kernel48ring(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         // workgroups per launch: one per item (the hardware hands a queued workgroup to whichever CU frees a slot: dynamic balance) rather than 512
         // resident ones walking static item ranges — same box, alternating: 774.4 / 774.5 -> 779.0 / 780.7 frames/s, 96->96 209.9 -> 204.4 us,
         // 192->192 180.3 -> 177.2 (768 workgroups: 707 frames/s — 1.5 rounds of uneven ranges).  EAGLE_CONV_AD_SLOTS=512 restores the persistent form.
         static const int slots = getenv("EAGLE_CONV_AD_SLOTS") ? atoi(getenv("EAGLE_CONV_AD_SLOTS")) : (1 << 30);
-        hipLaunchKernelGGL(fn, dim3(std::min(items, slots)), dim3(256), lds_bytes(precision, c), s, a);
+        // variant 19 (one workgroup per CU by its LDS footprint): persistent, so that the halo ring's prefetch runs on from item to item
+        hipLaunchKernelGGL(fn, dim3(std::min(items, c.variant == 19 ? 256 : slots)), dim3(256), lds_bytes(precision, c), s, a);
         HIP_CHECK(hipGetLastError());
         return;
     }

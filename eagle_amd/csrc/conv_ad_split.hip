@@ -24,6 +24,12 @@ ConvKernel conv_ad_split_kernel48sb(int n_res)         // Cout = 48: four pixel 
     return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
 }
 
+ConvKernel conv_ad_split_kernel48ring(int n_res)       // Cout = 48: four pixel groups (16 x 32 tile), two-deep halo ring, one persistent workgroup per CU (variant 19)
+{
+    static const ConvKernel fn[3] = {conv_split_ad_kernel<1, 4, 0, 1, false>, conv_split_ad_kernel<1, 4, 1, 1, false>, conv_split_ad_kernel<1, 4, 2, 1, false>};
+    return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
+}
+
 ConvKernel conv_ad_split_kernel_s2(bool wide, int n_res)      // stride 2 over the space-to-depth image (variants 10 / 11)
 {
     static const ConvKernel fn[2][3] = {

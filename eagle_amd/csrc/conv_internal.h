@@ -44,5 +44,6 @@ ConvKernel conv_ad_split_kernel48(int n_res);               // the same for Cout
 ConvKernel conv_ad_split_kernel_s2(bool wide, int n_res);    // stride 2 (variants 10 / 11 of the split family)
 ConvKernel conv_ad_split_kernel_s2t(bool wide, int n_res);   // TRUE stride 2 on a column-plane halo, single halo buffer: BN = 192 (variant 14) / BN = 96 with the K split (variant 15)
 ConvKernel conv_ad_split_kernel48sb(int n_res);             // Cout = 48, 16 x 32 tile, single halo buffer (variant 13)
+ConvKernel conv_ad_split_kernel48ring(int n_res);           // Cout = 48, 16 x 32 tile, two-deep halo ring, one persistent workgroup per CU (variant 19)
 
 }  // namespace eagle

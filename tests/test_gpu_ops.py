@@ -205,7 +205,7 @@ def test_conv_split_a_direct(cin, cout, shape, res, post):
 
 @pytest.mark.parametrize("shape", [(3, 37, 45), (1, 16, 16), (2, 135, 240)])
 @pytest.mark.parametrize("res,post", [(True, 1), (False, 0), (2, 1)])
-@pytest.mark.parametrize("form", ["12", "13"])
+@pytest.mark.parametrize("form", ["12", "13", "19"])
 def test_conv_split_a_direct_k_split_48(shape, res, post, form, monkeypatch):
     """The Cout = 48 forms of the split A-direct kernel: variant 12 (K split over wave pairs, partial accumulators exchanged through LDS) and
     variant 13 (four pixel groups, 16 x 32 tile, one halo buffer).  Selected through EAGLE_CONV_KQ / the tuned table; covered here either way."""

@@ -47,6 +47,11 @@ def main(argv=None):
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--precision", default="f32s", choices=["f16", "f32", "f32s"],
                     help="f32s (default): fp32-grade results on fp16 MFMAs (what the reference's .float() path computes); f16: fastest; f32: bit-exact fp32 MFMA")
+    ap.add_argument("--detector-precision", default=None, choices=["f16", "f32", "f32s"],
+                    help="family of the detector alone (default: the library's — exact fp32 next to f32s key-points, so that boxes / confidences / ids are the fp32 arithmetic's bit for bit)")
+    ap.add_argument("--allow-saturation", action="store_true",
+                    help="f32s stores activations with a range of +-4094; by default a run in which one was clipped fails (EAGLE_E_RANGE). With this flag it only warns "
+                         "(for a checkpoint with larger activations prefer --precision f32)")
     ap.add_argument("--batch", type=int, default=10)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--num-homography", type=int, default=1, help="homography solves per second (main.py:27: 1)")
@@ -83,13 +88,20 @@ def main(argv=None):
     if hs is None or ys is None:
         print("WARNING: running with seeded RANDOM network weights: the output has the reference's schema but no meaning", flush=True)
     model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
-                            precision=a.precision, device=a.device, seed=a.seed,
+                            precision=a.precision, detector_precision=a.detector_precision, allow_saturation=a.allow_saturation, device=a.device, seed=a.seed,
                             hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker, camera_motion=a.camera_motion or False,
                             reid=a.reid, reid_state_dict=({("reid." + k): v for k, v in load_state_dict(a.reid_weights).items()} if a.reid_weights else None))
     t0 = time.perf_counter()
     nh, nk = (a.fps, a.fps) if a.every_frame else (a.num_homography, a.num_keypoint_detection)
-    coordinates = model.get_coordinates(frames, a.fps, num_homography=nh, num_keypoint_detection=nk, verbose=False, calibration=a.calibration)
+    from . import lib
+    try:
+        coordinates = model.get_coordinates(frames, a.fps, num_homography=nh, num_keypoint_detection=nk, verbose=False, calibration=a.calibration)
+    except lib.EagleRangeError as e:
+        raise SystemExit(f"error: {e}\n(re-run with --precision f32, or with --allow-saturation to accept clipped activations)")
     dt = time.perf_counter() - t0
+    sat = model.handle.timings()
+    if sat.sat_events:
+        print(f"WARNING: {sat.sat_events} activation stores in {sat.sat_frames} frame(s) were clipped at +-4094 (f32s range); the affected frames are not fp32-grade", flush=True)
     os.makedirs(a.out, exist_ok=True)
     with open(os.path.join(a.out, "raw_coordinates.json"), "w") as f:
         json.dump(coordinates, f, default=float)

@@ -80,3 +80,23 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
                 assert "eo_prims" not in src or f.endswith((".hip", ".h")) and "oracle/eo_prims.c" in src, f
+
+
+def test_default_config_semantics_and_new_fields():
+    """Round 4: eagle_default_config = split-precision key-points + exact-fp32 detector; a caller that picks another family without naming the detector's
+    gets the detector in that family; explicit choices are kept; the saturation switch defaults to "fail loudly"; the header's error code and the Python
+    exception exist; EagleTimings carries the saturation counters inside its fixed size."""
+    import ctypes as C
+    from eagle_amd import lib
+    c = lib.default_config()
+    assert (c.precision, c.det_precision, c.allow_saturation) == (lib.PREC_F32S, lib.PREC_F32 + 1, 0)
+    assert lib.default_config(precision=lib.PREC_F16).det_precision == 0
+    assert lib.default_config(precision=lib.PREC_F32).det_precision == 0
+    assert lib.default_config(precision=lib.PREC_F32S).det_precision == lib.PREC_F32 + 1
+    assert lib.default_config(precision=lib.PREC_F16, det_precision=lib.PREC_F32S + 1).det_precision == lib.PREC_F32S + 1
+    assert lib.default_config(allow_saturation=1).allow_saturation == 1
+    assert issubclass(lib.EagleRangeError, lib.EagleError) and lib.E_RANGE == -8
+    hdr = open(os.path.join(ROOT, "include", "eagle.h")).read()
+    assert "#define EAGLE_E_RANGE (-8)" in hdr and "allow_saturation" in hdr and "sat_events" in hdr
+    assert C.sizeof(lib.EagleTimings) == 4 * 4 + 8 + 8 * 4          # total_ms, conv_ms, 2 counts, conv_flop, (sat_events, sat_frames, reserved[6])
+    assert lib.abi_sizes()[0] == C.sizeof(lib.EagleConfig)

@@ -75,7 +75,7 @@ def test_conv_parity(case, prec):
 @pytest.mark.parametrize("stack", ["1", "0"])
 @pytest.mark.parametrize("force", ["3,2,0", "3,1,0", "6,2,3", "3,1,3", "2,2,4", "1,1,4"])
 @pytest.mark.parametrize("shape,ks,st,cin,cout", [((5, 17, 30), 3, 1, 48, 96), ((4, 7, 45), 3, 1, 32, 48), ((3, 34, 61), 3, 2, 48, 96), ((6, 12, 20), 1, 1, 64, 96),
-                                                  ((7, 1, 1), 3, 1, 16, 48), ((2, 33, 37), 3, 2, 3, 48)])
+                                                  ((7, 1, 1), 3, 1, 16, 48), ((2, 33, 37), 3, 2, 3, 48), ((50, 17, 30), 3, 1, 32, 48)])
 def test_conv_f32_every_tiling_is_bit_exact(shape, ks, st, cin, cout, force, stack, monkeypatch):
     """The exact family's tilings (round 4): full / half / quarter tiles (variants 0 / 3 / 4), 16 x 16 or 8 x 32 sub-tile arrangement, and the
     batch tiled as ONE image of N (H + 1) rows for stride-1 layers (a tile may straddle several frames; the virtual zero row between two

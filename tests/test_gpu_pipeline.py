@@ -701,6 +701,25 @@ def test_f32s_full_size_clip_properties(state_dicts):
     assert ra[:148].tobytes() == rb.tobytes() == rb2.tobytes()
 
 
+def test_f32_family_is_batch_and_position_invariant_at_the_bench_batch(state_dicts):
+    """The exact family tiles a batch as ONE stacked image since round 4 (tiles straddle frames): its records must not depend on the device batch or on
+    a frame's position in it.  53 frames (4 distinct, tiled) through a batch-50 handle (one full batch + a ragged one of 3) against a batch-3 handle:
+    byte-identical records, every copy of a frame identical wherever it sits."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    base = np.stack([synth.frame(0, 1), synth.frame(0, 20), synth.noise_frame(3), synth.frame(2, 5)])
+    clip = np.ascontiguousarray(np.tile(base, (14, 1, 1, 1))[:53])
+    a = CoordinateModel(precision="f32", batch=50, hrnet_state_dict=hs, detector_state_dict=ys)
+    ra = a.process_records(clip); a.handle.close()
+    b = CoordinateModel(precision="f32", batch=3, hrnet_state_dict=hs, detector_state_dict=ys)
+    rb = b.process_records(clip[:9]); b.handle.close()
+    assert ra[:9].tobytes() == rb.tobytes()
+    for k in range(4):
+        first = ra[k].tobytes()
+        assert all(ra[j].tobytes() == first for j in range(k, 53, 4)), k
+
+
 def test_cfg3_full_size_clip_properties():
     """BASELINE.json's configs[2] at full size through the DEFAULT handle (1000 frames of 1920x1080, yolov8l@960 in the exact family + HRNet in the
     split family, device batch 25 — the bench's cfg3 run): every copy of a frame yields byte-identical records wherever it sits in the clip and in its

@@ -84,7 +84,7 @@ void conv_tile_weights(int precision, const ConvConfig& cfg, const float* w_hwio
 inline int prec_tensor_fmt(int precision) { return precision == EAGLE_PREC_F32 ? 1 : precision == EAGLE_PREC_F32S ? 2 : 0; }
 inline bool prec_is_f16_kernels(int precision) { return precision == EAGLE_PREC_F16 || precision == EAGLE_PREC_F32S; }
 // plain_epilogue: pre_act none, post_act none/ReLU, at most one residual, fp16 output (what the weight-stationary kernel implements)
-ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue = false, bool second_residual = false);
+ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue = false, bool second_residual = false, bool any_residual = true);
 
 // ---- other kernels ----------------------------------------------------------------------------------------
 struct LetterBox { int new_h, new_w, top, left, out_h, out_w; };

@@ -124,7 +124,7 @@ static const Tuned g_tuned_split[] = {       // EAGLE_PREC_F32S (tools/autotune_
 #include "conv_tuned_split.inc"
     {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
-ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue, bool second_residual)
+ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue, bool second_residual, bool any_residual)
 {
     // plain_epilogue: no activation before the residual adds, none / ReLU after them, fp16 output.  The weight-stationary kernels also need
     // at most one residual; the A-direct kernels take two.
@@ -170,6 +170,13 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         // (measured on MI355X: 48->48@135x240 305 / 551 us without / with residual against 273 / 322 us of the generic kernel — an 8 x 32 x 48 item is
         //  21 K-steps per wave, too little work against the exchange, the epilogue and three barriers; kept for the tuner, off by default)
         const bool kq_on = getenv("EAGLE_CONV_KQ") && atoi(getenv("EAGLE_CONV_KQ")) != 0;      // (read per call: the parity test switches it on)
+        // EAGLE_CONV_48NR=1 (measured, round 4): the Cout = 48 layers WITHOUT a residual operand (conv1 of every BasicBlock of HRNet's widest branch) on the
+        // 16 x 32 single-buffer A-direct form (variant 13), which is 6 % ahead of the 8 x 48 generic tile on that case in isolation (251 vs 268 us)
+        const bool nr48 = getenv("EAGLE_CONV_48NR") && atoi(getenv("EAGLE_CONV_48NR")) != 0;
+        if (sad_on && nr48 && !any_residual && plain_epilogue && ks == 3 && stride == 1 && cin_pad == 48 && cout_pad == 48 && wo > 64) {
+            ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = 13;
+            return q;
+        }
         if (sad_on && kq_on && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 48 == 0 && cout_pad % 48 == 0 && cout_pad % 96 != 0) {      // Cout = 48 (144, ...): K split over wave pairs
             ConvConfig q = c; q.kc = 16; q.nt = 3; q.variant = atoi(getenv("EAGLE_CONV_KQ")) == 13 ? 13 : atoi(getenv("EAGLE_CONV_KQ")) == 19 ? 19 : 12;
             return q;

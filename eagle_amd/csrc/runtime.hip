@@ -288,7 +288,7 @@ struct Builder {
             if (FILE* f = fopen(dump, "a")) { fprintf(f, "%d,%d,%d,%d,%d,%d,%d\n", ks, stride, x.c, cout_pad, x.h, x.w, N); fclose(f); }
         }
         ConvLaunch L;
-        L.cfg = conv_choose(prec, ks, stride, x.c, cout_pad, wo, pre == ACT_NONE && post <= ACT_RELU && !out_f32, r1 && r2);
+        L.cfg = conv_choose(prec, ks, stride, x.c, cout_pad, wo, pre == ACT_NONE && post <= ACT_RELU && !out_f32, r1 && r2, r1 || r2);
         if (!conv_supported(prec, L.cfg))
             fail(EAGLE_E_NOKERNEL, "%s: no kernel instance (ks=%d s=%d kc=%d nt=%d)", cname.c_str(), ks, stride, L.cfg.kc, L.cfg.nt);
         const size_t ne = conv_weight_elems(prec, L.cfg);
@@ -1880,7 +1880,7 @@ int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int
     const int ho = (h + 2 * (ks / 2) - ks) / stride + 1, wo = (w + 2 * (ks / 2) - ks) / stride + 1;
     ConvLaunch L;
     to_dev(net, precision, x, n, h, w, cin, cin_pad, L.x);
-    L.cfg = conv_choose(precision, ks, stride, cin_pad, cout_pad, wo, pre_act == ACT_NONE && post_act <= ACT_RELU, r1 && r2);
+    L.cfg = conv_choose(precision, ks, stride, cin_pad, cout_pad, wo, pre_act == ACT_NONE && post_act <= ACT_RELU, r1 && r2, r1 || r2);
     if (!conv_supported(precision, L.cfg)) fail(EAGLE_E_NOKERNEL, "no kernel instance ks=%d s=%d kc=%d nt=%d", ks, stride, L.cfg.kc, L.cfg.nt);
     std::vector<char> tiled(conv_weight_elems(precision, L.cfg) * (precision == EAGLE_PREC_F32 ? 4 : 2));
     conv_tile_weights(precision, L.cfg, w_hwio, cin, cout, tiled.data(), &L.descale);

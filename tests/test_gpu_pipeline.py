@@ -624,6 +624,25 @@ def test_default_handle_dense_detector_is_exception_free_cfg3(cfg3_case):
     assert sum(nd) > 100, nd
 
 
+def test_default_handle_on_a_small_frame_size(state_dicts):
+    """The same exception-free comparison on 640x360 frames (another letter-box geometry, the key-point resize enlarges instead of shrinking; batch 3 with
+    two frames: a ragged batch through the stacked exact tiling)."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    from oracle import pipeline
+    hs, ys = state_dicts
+    fr = np.stack([synth.frame(0, 3, 360, 640), synth.frame(1, 8, 360, 640)])
+    cm = CoordinateModel(batch=3, frame_hw=(360, 640), hrnet_state_dict=hs, detector_state_dict=ys)
+    recs = cm.process_records(fr)
+    cm.handle.close()
+    ora = pipeline.OracleModel(hs, ys, backend="c")
+    nd = []
+    for i, f in enumerate(fr):
+        oref, aux = ora.step(f, i)
+        nd.append(_default_handle_parity(recs[i], oref, aux, f"default handle 360p frame {i}", (360, 640)))
+    assert sum(nd) > 0, nd
+
+
 def test_default_handle_detector_half_equals_the_exact_family(state_dicts, frames):
     """GPU against GPU: every detection field of the default handle is byte-identical to the exact (fp32) handle's."""
     from eagle_amd.coordinate_model import CoordinateModel

@@ -154,6 +154,12 @@ def main():
 
     dist = torch = None
     dev_index = 0 if a.shared_gpu else local_rank
+    # CPU placement BEFORE the first GPU call (and after the CPU baseline child): this rank, the library's copy workers and the HIP runtime's helper
+    # threads run on the CPUs of the GPU's NUMA node (sysfs only; eagle_amd/shard.py::bind_rank_cpus, EAGLE_BIND_CPUS=0 disables)
+    from eagle_amd import shard as _shard                 # (pure Python: neither torch nor the HIP library is loaded by this import)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpu_binding = _shard.bind_rank_cpus(local_rank, local_world, rank_devs=[0] * local_world if a.shared_gpu else None)
+    log(f"rank {rank}: cpu binding {cpu_binding}")
     tdev = "cuda" if a.backend == "nccl" else "cpu"
     if multi:
         import torch                                       # BEFORE the HIP library is loaded: one ROCm runtime per process (lib.require_torch_first)
@@ -439,7 +445,8 @@ def main():
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}", "input": "pageable host memory (eagle_process_frames)",
                        "keypoint_precision": a.precision, "detector_precision": det_prec_name,
-                       "gather": "none" if not multi else gather_used, "hip_graph": bool(a.graph)},
+                       "gather": "none" if not multi else gather_used, "hip_graph": bool(a.graph), "cpu_binding_rank0": cpu_binding,
+                       "runtime": "torch-bundled ROCm (torch imported before libeagle_hip.so)" if multi else "/opt/rocm (torch-free process)"},
             "roofline": {"bound": "mfma", "kernel": f"{CONV_KERNEL[a.precision]} (the {n_conv // prof_steps} convolution launches per step of the key-point network's family)",
                          "achieved": round(achieved, 2), "peak": round(PEAK[a.precision], 1), "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[a.precision], 4),

@@ -136,7 +136,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
     if (precision == EAGLE_PREC_F32) {
         if (const char* f = getenv("EAGLE_F32_FORCE")) {    // "nt,wx,variant": parity tests of the tilings (every tiling gives the same bits)
             ConvConfig q = c; q.kc = (cin_pad < 16) ? 4 : 16;
-            if (sscanf(f, "%d,%d,%d", &q.nt, &q.wx, &q.variant) == 3 && cout_pad % (16 * q.nt) == 0 && find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
+            if (sscanf(f, "%d,%d,%d", &q.nt, &q.wx, &q.variant) == 3 && (q.wx == 1 || q.wx == 2) && q.nt >= 1 && cout_pad % (16 * q.nt) == 0 && find_inst(precision, q) && lds_bytes(precision, q) <= 160 * 1024) return q;
         }
         static const bool tuned32 = !(getenv("EAGLE_CONV_TUNED") && atoi(getenv("EAGLE_CONV_TUNED")) == 0);
         if (tuned32)

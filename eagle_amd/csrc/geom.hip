@@ -238,7 +238,10 @@ __device__ int dlt_homography_block(HomoShared& S, const double* src, const doub
         sM[0] += fabs(src[2 * i] - cM[0]); sM[1] += fabs(src[2 * i + 1] - cM[1]);
         sm[0] += fabs(dst[2 * i] - cm[0]); sm[1] += fabs(dst[2 * i + 1] - cm[1]);
     }
-    if (fabs(sM[0]) < DEPS || fabs(sM[1]) < DEPS || fabs(sm[0]) < DEPS || fabs(sm[1]) < DEPS) return 0;      // uniform
+    if (fabs(sM[0]) < DEPS || fabs(sM[1]) < DEPS || fabs(sm[0]) < DEPS || fabs(sm[1]) < DEPS) {              // uniform (every thread computed the same sums)
+        __syncthreads();                                   // no thread is still reading src / dst / the caller's shared state when the caller goes on to write it
+        return 0;
+    }
     sM[0] = n / sM[0]; sM[1] = n / sM[1]; sm[0] = n / sm[0]; sm[1] = n / sm[1];
     __syncthreads();                                       // (the previous user of S.jA / S.jV is done)
     if (tid < 81) {
@@ -302,6 +305,7 @@ __device__ int dlt_homography_block(HomoShared& S, const double* src, const doub
                     __syncthreads();
                 }
             }
+        __syncthreads();                                   // the sweep's last pairs may have passed without a barrier: every thread has read S.jd[p], S.jd[q] (they steer the branches above)
         if (tid < 9) { S.jb[tid] += S.jz[tid]; S.jd[tid] = S.jb[tid]; S.jz[tid] = 0.0; }
         __syncthreads();
     }

@@ -306,6 +306,12 @@ struct Builder {
         if (r1) L.r1 = *r1;
         if (r2) L.r2 = *r2;
         L.pre_act = pre; L.post_act = post; L.out_f32 = out_f32 ? 1 : 0;
+        // every convolution kernel addresses its tensors through raw buffer descriptors with 32-bit byte offsets: a tensor that reaches 2 GiB is
+        // refused HERE (eagle_finalize_weights returns the error), not at the first launch in the middle of a pipeline or a hipGraph capture
+        for (const TView* t : {&L.x, &L.y, r1 ? &L.r1 : nullptr, r2 ? &L.r2 : nullptr})
+            if (t && (size_t)t->n * t->h * t->w * t->cs * t->esize() >= ((size_t)1 << 31))
+                fail(EAGLE_E_INVALID, "%s: a %d x %d x %d x %d-channel tensor of this layer reaches 2 GiB at a device batch of %d frames (32-bit tensor offsets); use a smaller EagleConfig.batch",
+                     cname.c_str(), t->n, t->h, t->w, t->cs, N);
         L.am_slot = am_slot;
         if (prec == EAGLE_PREC_F32S && !out_f32 && !am_slot) L.sat_slot = &H->cur_sat;
         if (am_slot) { H->hm_chunks = conv_tiles_per_frame(L.cfg, ho, wo); H->fused_argmax = true; }
@@ -1113,9 +1119,17 @@ int eagle_default_config(EagleConfig* cfg)
     cfg->keypoint_conf = 0.3; cfg->detector_conf = 0.35; cfg->ransac_thresh = 5.0;
     cfg->detector_floor = 0.15f; cfg->nms_iou = 0.7f;
     cfg->ransac_max_iters = 2000; cfg->lm_iters = 10; cfg->use_graph = 0;
-    // the detector (1.4 % of the FLOP with yolov8n) in the exact fp32 family: boxes, confidences, classes, the NMS order and therefore every
-    // detection-index id (cm.py:598-627) equal the fp32 oracle's bit for bit; the key-point network stays in the split family
-    cfg->det_precision = EAGLE_PREC_F32 + 1;
+    // "auto" (resolved by eagle_create from the `precision` the caller ends up with): next to split-family key-points the detector (1.4 % of the
+    // FLOP with yolov8n) runs in the exact fp32 family — boxes, confidences, classes, the NMS order and therefore every detection-index id
+    // (cm.py:598-627) equal the fp32 oracle's bit for bit; next to any other `precision` it runs in that same family
+    cfg->det_precision = EAGLE_DET_PREC_AUTO;
+    return EAGLE_OK;
+}
+
+int eagle_resolve_config(EagleConfig* cfg)
+{
+    if (!cfg) return EAGLE_E_INVALID;
+    if (cfg->det_precision == EAGLE_DET_PREC_AUTO) cfg->det_precision = cfg->precision == EAGLE_PREC_F32S ? EAGLE_PREC_F32 + 1 : 0;
     return EAGLE_OK;
 }
 
@@ -1127,13 +1141,14 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     if (cfg->batch < 1 || cfg->frame_h < 32 || cfg->frame_w < 32) fail(EAGLE_E_INVALID, "bad batch/frame size");
     if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32 && cfg->precision != EAGLE_PREC_F32S) fail(EAGLE_E_INVALID, "bad precision");
     if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
-    if (cfg->det_precision < 0 || cfg->det_precision > EAGLE_PREC_F32S + 1) fail(EAGLE_E_INVALID, "bad detector precision");
+    if (cfg->det_precision < EAGLE_DET_PREC_AUTO || cfg->det_precision > EAGLE_PREC_F32S + 1) fail(EAGLE_E_INVALID, "bad detector precision");
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) fail(EAGLE_E_HIP, "device %d not present (%d visible)", cfg->device, ndev);
     HIP_CHECK(hipSetDevice(cfg->device));
     EagleHandle* nh = new EagleHandle;
     nh->cfg = *cfg;
+    eagle_resolve_config(&nh->cfg);                        // det_precision "auto" -> a family, from the precision the caller actually asked for
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_main, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_det, hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&nh->s_post, hipStreamNonBlocking));
@@ -1181,6 +1196,13 @@ void eagle_destroy(EagleHandle* h)
     for (auto e : h->ev_join) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {h->ev_pre, h->ev_det, h->ev_t0, h->ev_t1}) if (e) (void)hipEventDestroy(e);
     delete h;
+}
+
+int eagle_get_config(EagleHandle* h, EagleConfig* cfg)
+{
+    if (!h || !cfg) return EAGLE_E_INVALID;
+    *cfg = h->cfg;
+    return EAGLE_OK;
 }
 
 const char* eagle_last_error(EagleHandle* h) { return h ? h->err.c_str() : eagle::g_create_error.c_str(); }
@@ -1243,6 +1265,10 @@ int eagle_process_frames(EagleHandle* h, const uint8_t* bgr, int n, int64_t fram
     const size_t fsz = (size_t)fh * fw * 3;
     if (row_stride == 0) row_stride = (int64_t)fw * 3;
     if (frame_stride == 0) frame_stride = row_stride * fh;
+    // strides in bytes; a row must hold fw BGR pixels and the frames of one call must not overlap (the caller's view may be a crop of a wider
+    // surface or a decoder's padded plane: cm.py:568 hands over whatever view it holds).  Negative strides (flipped views) are not supported.
+    if (row_stride < (int64_t)fw * 3) fail(EAGLE_E_INVALID, "row_stride %lld is smaller than a row of %d BGR pixels (%d bytes)", (long long)row_stride, fw, fw * 3);
+    if (frame_stride < row_stride * (fh - 1) + (int64_t)fw * 3) fail(EAGLE_E_INVALID, "frame_stride %lld is smaller than a frame (%d rows of stride %lld)", (long long)frame_stride, fh, (long long)row_stride);
     // H2D on its own stream: the upload of batch k+1 overlaps the networks of batch k.  (The device staging buffer of parity p
     // was last read by batch k-2, whose records the host has already collected.)
     //   * caller memory that is already pinned (eagle_host_alloc, hipHostMalloc, hipHostRegister): DMA straight out of it;

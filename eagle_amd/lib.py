@@ -14,6 +14,7 @@ MAX_DET, N_LANDMARKS, MAX_KP = 300, 57, 87
 PREC_F16, PREC_F32, PREC_F32S = 0, 1, 2
 PRECISIONS = {"f16": PREC_F16, "f32": PREC_F32, "f32s": PREC_F32S}      # include/eagle.h EAGLE_PREC_*
 DET_VARIANTS = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
+DET_PREC_AUTO = -1                                                     # include/eagle.h EAGLE_DET_PREC_AUTO
 
 
 class EagleError(RuntimeError):
@@ -64,7 +65,6 @@ RESULT_DTYPE = np.dtype([("n_det", "<i4"), ("n_kp", "<i4"), ("n_candidates", "<i
                          ("kp", KP_DTYPE, MAX_KP), ("det", DET_DTYPE, MAX_DET)], align=True)
 
 _lib = None
-_gpu_touched = False      # a handle has been created in this process: the library's HIP runtime is initialised
 
 
 def require_torch_first():
@@ -72,10 +72,11 @@ def require_torch_first():
     to /opt/rocm's): when torch is imported BEFORE this library is loaded, the dynamic loader binds libeagle_hip.so and the dlopen'ed RCCL to
     torch's copies by SONAME — one runtime.  The other order maps /opt/rocm's runtime first and torch's second copy next to it (torch asks for
     "libamdhip64.so", which matches no SONAME): two HSA runtimes in one process, which is what aborted at interpreter exit in round 3
-    (DESIGN.md §8).  Called by every code path of this package that imports torch after a handle may exist."""
+    (DESIGN.md §8).  Called by every code path of this package that imports torch after the library may have been loaded.  The gate is the
+    dlopen itself (``load()``: it is libeagle_hip.so's NEEDED entry that maps /opt/rocm's libamdhip64), not the first handle."""
     import sys
-    if "torch" not in sys.modules and _gpu_touched:
-        raise EagleError("torch must be imported before eagle_amd.lib creates its first handle in a process that uses both "
+    if "torch" not in sys.modules and _lib is not None:
+        raise EagleError("torch must be imported before eagle_amd.lib loads libeagle_hip.so in a process that uses both "
                          "(two ROCm runtimes would be mapped: torch's bundled one and /opt/rocm's); import torch first, or keep the process torch-free")
 
 
@@ -97,6 +98,8 @@ def load():
     L.eagle_destroy.restype = None
     L.eagle_last_error.argtypes = [vp]
     L.eagle_last_error.restype = C.c_char_p
+    L.eagle_get_config.argtypes = [vp, C.POINTER(EagleConfig)]
+    L.eagle_resolve_config.argtypes = [C.POINTER(EagleConfig)]
     L.eagle_load_weights.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
     L.eagle_finalize_weights.argtypes = [vp]
     L.eagle_process_frames.argtypes = [vp, u8p, i32, i64, i64, vp]
@@ -139,7 +142,7 @@ def load():
     return L
 
 
-EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_destroy", "eagle_last_error", "eagle_load_weights",
+EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_destroy", "eagle_last_error", "eagle_get_config", "eagle_resolve_config", "eagle_load_weights",
            "eagle_finalize_weights", "eagle_process_frames", "eagle_process_device_frames", "eagle_device_alloc",
            "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
            "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
@@ -160,6 +163,14 @@ def debug(key, value=0, out=None):
     return out
 
 
+def resolve_config(cfg):
+    """A copy of cfg with the "auto" fields resolved the way eagle_create will (no GPU needed)."""
+    out = EagleConfig.from_buffer_copy(cfg)
+    if load().eagle_resolve_config(C.byref(out)):
+        raise EagleError("eagle_resolve_config failed")
+    return out
+
+
 def abi_sizes():
     o = (C.c_int32 * 4)()
     load().eagle_abi_sizes(o)
@@ -171,13 +182,11 @@ def _fp(a):
 
 
 def default_config(**kw):
-    """eagle_default_config + overrides.  The library's default is the split family with the detector in the exact fp32 family
-    (``det_precision = EAGLE_PREC_F32 + 1``); a caller that picks another ``precision`` without naming ``det_precision`` gets the
-    detector in that same family (``det_precision = 0``)."""
+    """eagle_default_config + overrides: a thin pass-through.  The library's default ``det_precision`` is EAGLE_DET_PREC_AUTO (-1), which
+    eagle_create resolves from ``precision``: the exact fp32 family next to split-family key-points, otherwise the key-point family
+    (``Handle.cfg`` holds the resolved value)."""
     cfg = EagleConfig()
     load().eagle_default_config(C.byref(cfg))
-    if "precision" in kw and kw["precision"] != PREC_F32S and "det_precision" not in kw:
-        kw = dict(kw, det_precision=0)
     for k, v in kw.items():
         if k == "det_variant" and isinstance(v, str):
             v = DET_VARIANTS[v]
@@ -194,11 +203,12 @@ class Handle:
         self.L = load()
         self.cfg = cfg or default_config(**kw)
         self._h = C.c_void_p()
-        global _gpu_touched
-        _gpu_touched = True
         rc = self.L.eagle_create(C.byref(self.cfg), C.byref(self._h))
         if rc:
             raise EagleError(f"eagle_create failed ({rc}): {self.L.eagle_last_error(None).decode()}")
+        resolved = EagleConfig()
+        self._check(self.L.eagle_get_config(self._h, C.byref(resolved)), "get_config")
+        self.cfg = resolved                                 # det_precision as the library resolved it (EAGLE_DET_PREC_AUTO -> a family)
 
     def _check(self, rc, what):
         if rc == E_RANGE:
@@ -232,18 +242,33 @@ class Handle:
     def finalize_weights(self):
         self._check(self.L.eagle_finalize_weights(self._h), "finalize_weights")
 
-    def process(self, frames, out=None):
-        """frames: uint8 [n,h,w,3] BGR (host).  -> structured array [n] of RESULT_DTYPE (``out``: optional preallocated result array)."""
-        frames = np.ascontiguousarray(frames, np.uint8)
+    def process(self, frames, out=None, strides=None):
+        """frames: uint8 [n,h,w,3] BGR (host).  -> structured array [n] of RESULT_DTYPE (``out``: optional preallocated result array).
+
+        The array is handed over AS THE VIEW IT IS (cm.py:568 passes whatever view the caller holds): a crop of a wider surface or a decoder's
+        padded plane goes to eagle_process_frames with its own frame / row strides, no host-side copy.  Only views whose pixels are not packed
+        BGR triples, whose strides are negative or whose frames overlap are made contiguous first.  ``strides=(frame_stride, row_stride)`` in
+        bytes overrides what is passed (tests of the boundary's argument checks)."""
+        frames = np.asarray(frames)
+        if frames.dtype != np.uint8:
+            frames = frames.astype(np.uint8)
         if frames.ndim == 3:
             frames = frames[None]
         n, h, w, c = frames.shape
         if (h, w, c) != (self.cfg.frame_h, self.cfg.frame_w, 3):
             raise EagleError(f"frame shape {(h, w, c)} does not match the handle ({self.cfg.frame_h}, {self.cfg.frame_w}, 3)")
+        fs, rs, ps, cs = frames.strides
+        if n == 1:
+            fs = max(fs, rs * (h - 1) + 3 * w)              # numpy reports any stride for a length-1 axis
+        if not (cs == 1 and ps == 3 and rs >= 3 * w and fs >= rs * (h - 1) + 3 * w):
+            frames = np.ascontiguousarray(frames)
+            fs, rs = h * w * 3, w * 3
+        if strides is not None:
+            fs, rs = strides
         if out is None:
             out = np.zeros(n, RESULT_DTYPE)
         assert out.dtype == RESULT_DTYPE and len(out) >= n and out.flags.c_contiguous
-        self._check_records(self.L.eagle_process_frames(self._h, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, 0, 0,
+        self._check_records(self.L.eagle_process_frames(self._h, C.cast(frames.ctypes.data, C.POINTER(C.c_uint8)), n, int(fs), int(rs),
                                                         out.ctypes.data_as(C.c_void_p)), "process_frames", out)
         return out
 
@@ -256,6 +281,15 @@ class Handle:
         self._check(self.L.eagle_host_alloc(self._h, nbytes, C.byref(p)), "host_alloc")
         buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
         a = np.frombuffer(buf, np.uint8, nbytes).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_buffer(self, nbytes):
+        """uint8 [nbytes] in pinned host memory (eagle_host_alloc) for callers that lay frames out themselves (row / frame pitch).  host_free(array)."""
+        p = C.c_void_p()
+        self._check(self.L.eagle_host_alloc(self._h, int(nbytes), C.byref(p)), "host_alloc")
+        a = np.frombuffer((C.c_uint8 * max(int(nbytes), 1)).from_address(p.value), np.uint8, int(nbytes))
         self._pinned = getattr(self, "_pinned", {})
         self._pinned[a.ctypes.data] = p
         return a

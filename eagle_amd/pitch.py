@@ -4,7 +4,7 @@ Own emission of the data the reference keeps in ``eagle/utils/pitch.py:1-60`` (i
 ``:65`` (NOT_ON_PLANE) and ``:209-267`` (UEFA 105 x 68 m world coordinates).  One row per landmark, in
 heat-map index order; ``WORLD_ORDER`` records the insertion order of the reference's GROUND_TRUTH_POINTS
 dict because that order decides the line-group iteration order of the keypoint synthesis
-(``eagle/models/coordinate_model.py:82-90,169-183``).  ``tests/test_pitch.py`` checks every value against
+(``eagle/models/coordinate_model.py:82-90,169-183``).  ``tests/test_pitch_weights_abi.py::test_pitch_tables_match_reference_dump`` checks every value against
 ``tests/golden/pitch_tables.json`` (dumped from the reference module by ``tests/golden/make_golden.py``).
 
 The same table is compiled into the C-ABI library (``csrc/pitch_table.h`` is generated from this file by

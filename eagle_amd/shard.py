@@ -102,3 +102,98 @@ def gather_clip_records(local_clips, clip_lengths, rank, world, handle=None, tra
             out.append(allr[off: off + clip_lengths[k]])
             off += clip_lengths[k]
     return out
+
+
+# ---- CPU placement of a rank (round 5; VERDICT r4 task 1c) -------------------------------------------------------------------------------------------
+# One process per GPU feeds its GPU from pageable host memory through the library's copy workers (EAGLE_COPY_THREADS, default 8) and a pinned staging
+# ring: at N = 8 that is 64 memcpy threads and 8 DMA sources which the scheduler would otherwise place anywhere on a two-socket host.  Before its first
+# GPU call a rank pins itself (and therefore every thread it creates later: the copy pool, the HIP runtime's helpers) to the CPUs of the NUMA node its
+# GPU hangs off.  Everything here reads sysfs only — no HIP call, so it can run before the GPU is initialised — and is testable against a fake tree.
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> {0, 1, 2, 3, 8, 10, 11} (the format of /sys/devices/system/node/node*/cpulist)."""
+    cpus = set()
+    for part in (text or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def visible_gpu_numa_nodes(sysfs="/sys", env=None):
+    """NUMA node of every HIP-visible GPU, in HIP device order, from the KFD topology (GPU nodes in node order = HIP's enumeration;
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES as integer lists are honoured).  An entry is None where sysfs does not say (-1 on single-node hosts)."""
+    import os
+    env = os.environ if env is None else env
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        ids = sorted(int(d) for d in os.listdir(base) if d.isdigit())
+    except OSError:
+        return []
+    gpus = []
+    for i in ids:
+        props = dict(ln.split(None, 1) for ln in (_read(os.path.join(base, str(i), "properties")) or "").splitlines() if " " in ln)
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue                                          # a CPU node
+        minor = props.get("drm_render_minor", "").strip()
+        node = _read(os.path.join(sysfs, "class", "drm", f"renderD{minor}", "device", "numa_node")) if minor else None
+        gpus.append(int(node) if node not in (None, "") and int(node) >= 0 else None)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):        # applied in that order by the runtime
+        v = env.get(var)
+        if v:
+            try:
+                gpus = [gpus[int(t)] for t in v.split(",") if t.strip() != ""]
+            except (ValueError, IndexError):
+                return []                                     # UUID lists etc.: do not guess
+    return gpus
+
+
+def plan_rank_cpus(local_rank, local_world, allowed, sysfs="/sys", env=None, min_slice=4, rank_devs=None):
+    """The CPU set local rank `local_rank` of `local_world` ranks on this host should run on, as (sorted list, reason).
+    allowed: the CPUs the process may use now (os.sched_getaffinity); rank_devs: HIP device of every local rank (default: rank r uses device r).
+    Policy: the CPUs of the GPU's NUMA node (intersected with `allowed`); when several local ranks share that node and it holds at least `min_slice`
+    CPUs per rank, a contiguous slice of it per rank (the copy workers of two ranks then never share a core); without NUMA information an even
+    contiguous split of `allowed` over the local ranks under the same condition, else no change."""
+    import os
+    allowed = sorted(allowed)
+    devs = list(range(local_world)) if rank_devs is None else list(rank_devs)
+    nodes = visible_gpu_numa_nodes(sysfs, env)
+    node_of = [nodes[d] if 0 <= d < len(nodes) else None for d in devs]
+    node = node_of[local_rank] if local_rank < len(node_of) else None
+    if node is not None:
+        cpus = sorted(parse_cpulist(_read(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist"))) & set(allowed))
+        if cpus:
+            sharers = [r for r in range(local_world) if node_of[r] == node]
+            if len(sharers) > 1 and len(cpus) >= min_slice * len(sharers):
+                k, m = sharers.index(local_rank), len(sharers)
+                return cpus[len(cpus) * k // m: len(cpus) * (k + 1) // m], f"numa node {node}, slice {k + 1}/{m}"
+            return cpus, f"numa node {node}"
+    if local_world > 1 and len(allowed) >= min_slice * local_world:
+        k = local_rank
+        return allowed[len(allowed) * k // local_world: len(allowed) * (k + 1) // local_world], f"no NUMA information: even split {k + 1}/{local_world}"
+    return allowed, "no NUMA information: unchanged"
+
+
+def bind_rank_cpus(local_rank, local_world, sysfs="/sys", env=None, rank_devs=None, min_slice=4):
+    """Apply plan_rank_cpus to this process (os.sched_setaffinity; threads created afterwards inherit it).  Call BEFORE the first GPU call and before
+    the library's copy pool exists.  EAGLE_BIND_CPUS=0 leaves the mask alone.  Returns a small report for the bench line."""
+    import os
+    before = sorted(os.sched_getaffinity(0))
+    if (os.environ if env is None else env).get("EAGLE_BIND_CPUS", "1") == "0":
+        return {"applied": False, "reason": "EAGLE_BIND_CPUS=0", "cpus": len(before)}
+    cpus, reason = plan_rank_cpus(local_rank, local_world, before, sysfs, env, min_slice, rank_devs)
+    applied = False
+    if cpus and cpus != before:
+        os.sched_setaffinity(0, cpus)
+        applied = True
+    now = sorted(os.sched_getaffinity(0))
+    return {"applied": applied, "reason": reason, "cpus": len(now), "first": now[0], "last": now[-1]}

@@ -43,6 +43,8 @@ extern "C" {
                                   three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi) into an fp32 accumulator: the error of an fp32 summation in
                                   another order, at 3/16 of the fp32 MFMA's cost per product */
 
+#define EAGLE_DET_PREC_AUTO (-1) /* EagleConfig::det_precision: chosen from `precision` by eagle_create */
+
 #define EAGLE_DET_N 0
 #define EAGLE_DET_S 1
 #define EAGLE_DET_M 2
@@ -67,9 +69,11 @@ typedef struct EagleConfig {
     int32_t ransac_max_iters;  /* 2000  cv2 default */
     int32_t lm_iters;          /* 10    cv2 default */
     int32_t use_graph;         /* 1: capture the per-batch step into a hipGraph and replay it */
-    int32_t det_precision;     /* 0: the detector runs in `precision`; otherwise EAGLE_PREC_* + 1 for the detector alone.  eagle_default_config sets
-                                  EAGLE_PREC_F32 + 1: key-points in the split family, the detector (1.4 % of the FLOP with yolov8n) in the exact fp32
-                                  family, so that boxes, confidences, classes, NMS order and detection-index ids are the fp32 oracle's bit for bit */
+    int32_t det_precision;     /* 0: the detector runs in `precision`; EAGLE_PREC_* + 1: that family for the detector alone; EAGLE_DET_PREC_AUTO (what
+                                  eagle_default_config sets; resolved by eagle_create): EAGLE_PREC_F32 + 1 when `precision` is EAGLE_PREC_F32S — key-points
+                                  in the split family, the detector (1.4 % of the FLOP with yolov8n) in the exact fp32 family, so that boxes, confidences,
+                                  classes, NMS order and detection-index ids are the fp32 oracle's bit for bit — and 0 for any other `precision` (a caller
+                                  that takes the defaults and only sets precision = EAGLE_PREC_F16 gets BOTH networks in the fast family) */
     int32_t allow_saturation;  /* EAGLE_PREC_F32S: 0 (default): a call in which an activation store was clipped at +-4094 returns EAGLE_E_RANGE;
                                   1: it returns EAGLE_OK and only flags the frames (EagleFrameResult.pad[1]) and counts them (EagleTimings) */
     int32_t reserved[5];
@@ -121,6 +125,8 @@ int eagle_default_config(EagleConfig* cfg);
 int eagle_create(const EagleConfig* cfg, EagleHandle** out);
 void eagle_destroy(EagleHandle* h);
 const char* eagle_last_error(EagleHandle* h);   /* h may be NULL: last error of eagle_create */
+int eagle_resolve_config(EagleConfig* cfg);     /* in place, no GPU needed: what eagle_create will make of the "auto" fields (det_precision) */
+int eagle_get_config(EagleHandle* h, EagleConfig* cfg);   /* the handle's configuration as eagle_create resolved it (det_precision no longer "auto") */
 
 /* Weights: state-dict tensors by their reference names, fp32, PyTorch layouts
  *   HRNet + head: "unnormalized_model.0.<...>", "unnormalized_model.1.{weight,bias}" (kh.py:559-562)
@@ -129,7 +135,8 @@ const char* eagle_last_error(EagleHandle* h);   /* h may be NULL: last error of 
 int eagle_load_weights(EagleHandle* h, const char* name, const float* data, const int64_t* shape, int ndim);
 int eagle_finalize_weights(EagleHandle* h);
 
-/* The hot path: n BGR uint8 HWC frames (host memory, row stride in bytes) -> n records.  This is the call that replaces the reference's
+/* The hot path: n BGR uint8 HWC frames (host memory) -> n records.  frame_stride / row_stride in bytes, 0 = dense ([n, h, w, 3] contiguous); a
+ * row_stride below 3 * frame_w, a frame_stride below (frame_h - 1) * row_stride + 3 * frame_w or a negative stride is EAGLE_E_INVALID.  This is the call that replaces the reference's
  * per-frame loop over host frames (cm.py:277; frames come from eagle/utils/io.py::read_video).  The upload of batch k+1 overlaps the
  * networks of batch k.  Frames in pinned memory (eagle_host_alloc: what a decoder should write into) are DMA'd in place; frames in
  * pageable memory are first copied into a pinned ring by a few worker threads of the handle (EAGLE_COPY_THREADS, default 8). */
@@ -139,7 +146,7 @@ int eagle_host_alloc(EagleHandle* h, int64_t bytes, void** ptr);   /* pinned hos
 int eagle_host_free(EagleHandle* h, void* ptr);
 
 /* Same, inputs already resident in HBM (device pointer, dense [n,h,w,3]); records still land on the host.
- * This is the entry bench.py times ("inputs resident in HBM when the timed region starts"). */
+ * bench.py reports this entry as `resident`; its `value` is eagle_process_frames from pageable host memory. */
 int eagle_process_device_frames(EagleHandle* h, const void* d_bgr, int n, EagleFrameResult* out);
 int eagle_device_alloc(EagleHandle* h, int64_t bytes, void** dptr);
 int eagle_device_free(EagleHandle* h, void* dptr);

@@ -75,7 +75,7 @@ def loop_records(per_frame, fps, num_homography, frame_h, frame_w):
                 compute_homography = True
             else:
                 Hn, mask = P.find_homography_ransac(img_pts, world_pts, 5.0)
-                if Hn is None:                                          # cm.py:354-357: RHO is not restated, LMEDS is
+                if Hn is None:                                          # cm.py:354-357: RANSAC -> RHO -> LMEDS; both fall-backs are restated (oracle/eo_prims.c), see step() — this loop serves LMEDS
                     Hn, mask = P.find_homography(img_pts, world_pts, 4)
                 if Hn is not None:
                     prev_keypoints = {k: v for k, v, m in zip(used, img_pts.tolist(), mask.flatten()) if m}

@@ -89,14 +89,39 @@ def test_default_config_semantics_and_new_fields():
     import ctypes as C
     from eagle_amd import lib
     c = lib.default_config()
-    assert (c.precision, c.det_precision, c.allow_saturation) == (lib.PREC_F32S, lib.PREC_F32 + 1, 0)
-    assert lib.default_config(precision=lib.PREC_F16).det_precision == 0
-    assert lib.default_config(precision=lib.PREC_F32).det_precision == 0
-    assert lib.default_config(precision=lib.PREC_F32S).det_precision == lib.PREC_F32 + 1
-    assert lib.default_config(precision=lib.PREC_F16, det_precision=lib.PREC_F32S + 1).det_precision == lib.PREC_F32S + 1
+    assert (c.precision, c.det_precision, c.allow_saturation) == (lib.PREC_F32S, lib.DET_PREC_AUTO, 0)
+    # round 5: the default is resolved INSIDE the C library (eagle_create -> eagle_resolve_config), so a C-ABI caller that takes
+    # eagle_default_config and only sets cfg.precision = EAGLE_PREC_F16 gets both networks in the fast family; lib.default_config is a pass-through
+    raw = lib.EagleConfig(); lib.load().eagle_default_config(C.byref(raw))
+    raw.precision = lib.PREC_F16
+    assert raw.det_precision == lib.DET_PREC_AUTO and lib.resolve_config(raw).det_precision == 0
+    assert lib.resolve_config(c).det_precision == lib.PREC_F32 + 1
+    assert lib.resolve_config(lib.default_config(precision=lib.PREC_F16)).det_precision == 0
+    assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32)).det_precision == 0
+    assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32S)).det_precision == lib.PREC_F32 + 1
+    assert lib.resolve_config(lib.default_config(precision=lib.PREC_F16, det_precision=lib.PREC_F32S + 1)).det_precision == lib.PREC_F32S + 1
+    assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32S, det_precision=0)).det_precision == 0
     assert lib.default_config(allow_saturation=1).allow_saturation == 1
     assert issubclass(lib.EagleRangeError, lib.EagleError) and lib.E_RANGE == -8
     hdr = open(os.path.join(ROOT, "include", "eagle.h")).read()
     assert "#define EAGLE_E_RANGE (-8)" in hdr and "allow_saturation" in hdr and "sat_events" in hdr
     assert C.sizeof(lib.EagleTimings) == 4 * 4 + 8 + 8 * 4          # total_ms, conv_ms, 2 counts, conv_flop, (sat_events, sat_frames, reserved[6])
     assert lib.abi_sizes()[0] == C.sizeof(lib.EagleConfig)
+
+
+def test_torch_after_loading_the_library_is_refused():
+    """it is the dlopen of libeagle_hip.so (its NEEDED libamdhip64.so.7 maps /opt/rocm's runtime), not the first handle, after which a
+    torch import maps a second runtime: load() / default_config() / comm_unique_id() alone must trip the guard."""
+    import subprocess
+    import sys
+    root = ROOT
+    code = ("import sys, numpy as np\n"
+            "from eagle_amd import lib, shard\n"
+            "lib.default_config()\n"
+            "assert 'torch' not in sys.modules\n"
+            "try:\n"
+            "    shard.gather_records(np.zeros(1, lib.RESULT_DTYPE), 2, 0, 2, transport='dist')\n"
+            "except lib.EagleError as e:\n"
+            "    assert 'torch must be imported before' in str(e); print('REFUSED')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "REFUSED" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])

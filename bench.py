@@ -103,6 +103,50 @@ def cpu_baseline_subprocess(a):
         return {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"cpu baseline child failed: {e!r}"}
 
 
+def latency_table(lib, weights, hs, ys, a, dev_index, frames, calls, batches=(1, 2, 4, 8), modes=None):
+    """Small-batch behaviour of the DEFAULT handle (north_star's API is Processor.process(frame); the reference's caller is a frame-by-frame loop,
+    cm.py:277): one `eagle_process_frames` call of B frames from pageable host memory -> records on the host, per call.  For every B a fresh handle
+    with EagleConfig.batch = B; median and p99 wall time over `calls` calls (after 10 warm-up calls), frames/s = B / median.  modes: list of
+    (label, env overrides, config overrides)."""
+    rows = []
+    modes = modes or [("default", {}, {})]
+    for B in batches:
+        for label, env, kw in modes:
+            saved = {k: os.environ.get(k) for k in env}
+            for k, v in env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            try:
+                h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz, batch=B,
+                               precision=lib.PRECISIONS[a.precision], **kw)
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            weights.load_into(h, [hs, ys])
+            out = np.zeros(B, lib.RESULT_DTYPE)
+            nf = len(frames) - B + 1
+            for k in range(10):
+                h.process(frames[(k * B) % nf:][:B], out)
+            ts = np.empty(calls)
+            for k in range(calls):
+                f = frames[(k * B) % nf:][:B]
+                t0 = time.perf_counter()
+                h.process(f, out)
+                ts[k] = time.perf_counter() - t0
+            h.close()
+            ts.sort()
+            med, p99 = float(np.median(ts)), float(ts[min(calls - 1, int(np.ceil(0.99 * calls)) - 1)])
+            rows.append({"frames_per_call": B, "mode": label, "median_ms": round(med * 1e3, 3), "p99_ms": round(p99 * 1e3, 3), "min_ms": round(float(ts[0]) * 1e3, 3),
+                         "frames_per_s": round(B / med, 1), "calls": calls})
+            log(f"latency B={B} {label}: median {med * 1e3:.2f} ms, p99 {p99 * 1e3:.2f} ms, {B / med:.1f} frames/s")
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +173,8 @@ def main():
     ap.add_argument("--cfg3-frames", type=int, default=1000, help="frames of the configs[2] run (1920x1080, yolov8l@960; 0: skip)")
     ap.add_argument("--cadence", type=int, default=0, metavar="FPS", help="also time the reference's default cadence on the same clip: get_coordinates(frames, FPS, num_homography=1, "
                     "num_keypoint_detection=3) = HRNet every int(FPS/3)-th frame, optical-flow propagation in between (stateful; reported as reference_cadence, never as value)")
+    ap.add_argument("--latency-calls", type=int, default=200, help="calls per row of the small-batch latency table (0: skip)")
+    ap.add_argument("--latency-only", action="store_true", help="developer: print only the small-batch latency table (all modes: multi-stream / hipGraph on and off)")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --shared-gpu: dev test of the multi-rank path on one GPU)")
     ap.add_argument("--shared-gpu", action="store_true", help="every rank uses HIP device 0 (developer test only)")
@@ -178,6 +224,12 @@ def main():
     B, K, W = a.batch, a.steps, a.warmup
     hs = weights.make_hrnet_state_dict(0)
     ys = weights.make_yolo_state_dict(a.detector, 0)
+    if a.latency_only:
+        fr = synth.clip(seed=0, n=max(a.distinct, 16), h=a.height, w=a.width)
+        modes = [("1stream", {"EAGLE_MULTI_STREAM": None}, {}), ("multi_stream", {"EAGLE_MULTI_STREAM": "1"}, {}),
+                 ("1stream+graph", {"EAGLE_MULTI_STREAM": None}, {"use_graph": 1}), ("multi_stream+graph", {"EAGLE_MULTI_STREAM": "1"}, {"use_graph": 1})]
+        print(json.dumps({"latency": latency_table(lib, weights, hs, ys, a, dev_index, fr, a.latency_calls, modes=modes)}), flush=True)
+        return
     det_kw = {} if a.det_precision == "default" else {"det_precision": lib.PRECISIONS[a.det_precision] + 1}
     h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
                    batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if a.graph else 0, **det_kw)

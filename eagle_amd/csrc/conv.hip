@@ -32,11 +32,12 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : c.variant == 4 ? 1 : c.variant == 18 ? 6 : 4; }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
-static bool conv_ad(const ConvConfig& c) { return (c.variant >= 8 && c.variant <= 15) || c.variant == 19; }
+static bool conv_ad_m32(const ConvConfig& c) { return c.variant == 21 || c.variant == 22; }      // split family on v_mfma_f32_32x32x16_f16 (conv_ad_split32.inc): 21 = BN 192, tile 4 x 32; 22 = BN 96, tile 8 x 32
+static bool conv_ad(const ConvConfig& c) { return (c.variant >= 8 && c.variant <= 15) || c.variant == 19 || conv_ad_m32(c); }
 static bool conv_ad_s2t(const ConvConfig& c) { return c.variant == 14 || c.variant == 15; }      // TRUE stride 2 on a column-plane halo (14: BN 192; 15: BN 96, K split over wave pairs)
 static bool conv_ad_s2d(const ConvConfig& c) { return c.variant == 10 || c.variant == 11; }      // stride 2 over the space-to-depth image (variants 14 / 15: true stride 2, the stride-1 weight image)
-static int conv_ad_rows(const ConvConfig& c) { return (c.variant == 8 || c.variant == 10 || conv_ad_s2t(c)) ? 4 : (c.variant == 13 || c.variant == 19) ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
-static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10 || c.variant == 14; }
+static int conv_ad_rows(const ConvConfig& c) { return (c.variant == 8 || c.variant == 10 || c.variant == 21 || conv_ad_s2t(c)) ? 4 : (c.variant == 13 || c.variant == 19) ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
+static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10 || c.variant == 14 || c.variant == 21; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
@@ -51,6 +52,10 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
         const size_t operands = (size_t)f16_ni(c.ks, c.kc) * 4 * bn * 16 + (size_t)hh * hw * f16_ps(c.kc);
         const size_t strips = (size_t)4 * conv_pw(c) * 16 * (bn * 2 + 16);        // output transpose, one strip per wave
         return conv_ws(c) ? operands + strips + 16 : std::max(operands + 16, strips);
+    }
+    if (precision == EAGLE_PREC_F32S && conv_ad_m32(c)) {  // 80-byte halo records, two-deep ring, strips of 32 pixels x 32 channels x 4 bytes
+        const int slabs = (((conv_ad_rows(c) + 2) * 34 * 80 + 1023) / 1024 + 3) / 4 * 4;
+        return (size_t)2 * slabs * 1024 + 4 * 32 * 144;
     }
     if (precision == EAGLE_PREC_F32S && conv_ad(c)) {      // same halo ring as the fp16 kernel (16 logical channels = the 96-byte record), strips of 16 pixels x 48 channels x 4 bytes
         const int hpix = conv_ad_s2t(c) ? (2 * conv_ad_rows(c) + 1) * 66 : (conv_ad_rows(c) + 2) * 34;      // variants 14 / 15: 9 rows x (33 even + 33 odd columns)
@@ -91,7 +96,9 @@ static const Inst g_ad_inst[] = {
     // split family, TRUE stride 2 on an even / odd column-plane halo, the stride-1 weight image (variant 14: BN = 192, tile 4 x 32, one halo buffer)
     {EAGLE_PREC_F32S, 3, 2, 16, 12, 14, nullptr},
     // the same with BN = 96: two Cout groups, the K dimension split over wave pairs (variant 15)
-    {EAGLE_PREC_F32S, 3, 2, 16, 6, 15, nullptr}};
+    {EAGLE_PREC_F32S, 3, 2, 16, 6, 15, nullptr},
+    // split family, stride 1, on v_mfma_f32_32x32x16_f16 (round 5, conv_ad_split32.inc): BN = 192 (variant 21) / BN = 96 (variant 22)
+    {EAGLE_PREC_F32S, 3, 1, 16, 12, 21, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 22, nullptr}};
 
 const Inst* conv_inst_part(int part, int* n)
 {
@@ -190,6 +197,14 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
             if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 14; } else { q.nt = 6; q.variant = 15; }
             return q;
         }
+        // round 5: the 32x32x16 form of the A-direct kernel (variants 21 / 22) for the 3x3 stride-1 layers with Cout = 96 k; any Cin = 16 k.  EAGLE_CONV_M32: 0 off,
+        // 1 both forms, 2 only BN = 192 (variant 21), 3 only BN = 96 (variant 22)
+        static const int m32 = getenv("EAGLE_CONV_M32") ? atoi(getenv("EAGLE_CONV_M32")) : 0;
+        if (sad_on && m32 && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 16 == 0 && cout_pad % 96 == 0) {
+            ConvConfig q = c; q.kc = 16;
+            if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 21; } else { q.nt = 6; q.variant = 22; }
+            if ((q.variant == 21 && m32 != 3) || (q.variant == 22 && m32 != 2)) return q;
+        }
         if (tuned_on)
             for (const Tuned& t : g_tuned_split)
                 if (t.ks == ks && t.s == stride && t.cin == cin_pad && t.cout == cout_pad && t.wo == wo) {
@@ -272,6 +287,7 @@ size_t conv_weight_elems(int precision, const ConvConfig& c)
     const int bn = c.nt * 16, nblk = c.cout_pad / bn, nch = c.cin / c.kc;
     if (precision == EAGLE_PREC_F16) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 4 * bn * 8;
     if (precision == EAGLE_PREC_F32S && conv_ad_s2d(c)) return (size_t)nblk * (4 * c.cin / 16) * 6 * 4 * bn * 8;      // 6 K-steps per 16-channel chunk of the space-to-depth image
+    if (precision == EAGLE_PREC_F32S && conv_ad_m32(c)) return (size_t)nblk * (c.cin / 16) * 18 * (bn / 32) * 512;      // 18 steps (tap, hi | lo) per 16-channel chunk, one 1-KiB fragment per 32 output channels
     if (precision == EAGLE_PREC_F32S && conv_ad(c)) return (size_t)nblk * (c.cin / 16) * 14 * 4 * bn * 8;   // 14 K-steps per 16-channel chunk
     if (precision == EAGLE_PREC_F32S) return (size_t)nblk * nch * f16_ni(c.ks, c.kc) * 2 * 4 * bn * 8;      // fp16 elements: a hi and a lo block per K-step
     return (size_t)nblk * nch * c.ks * c.ks * (c.kc / 4) * 4 * bn;
@@ -313,6 +329,22 @@ void conv_tile_weights(int precision, const ConvConfig& c, const float* w, int c
                                     const _Float16 hi = (_Float16)v;
                                     *d++ = k < 4 ? hi : (_Float16)(v - (float)hi);
                                 }
+            return;
+        }
+        if (conv_ad_m32(c)) {
+            // 32x32x16 form: [Cout block][16-channel chunk][tap 0..8][hi | lo][BN / 32 blocks][lane 0..63][8]: lane l of a block's A fragment holds output
+            // channel (l & 31) of the block and the chunk's 8-channel group (l >> 5)
+            for (int b = 0; b < nblk; ++b)
+                for (int ch = 0; ch < c.cin / 16; ++ch)
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int part = 0; part < 2; ++part)
+                            for (int mb = 0; mb < bn / 32; ++mb)
+                                for (int l = 0; l < 64; ++l)
+                                    for (int j = 0; j < 8; ++j) {
+                                        const float v = W(tap, ch * 16 + (l >> 5) * 8 + j, b * bn + mb * 32 + (l & 31)) * scale;
+                                        const _Float16 hi = (_Float16)v;
+                                        *d++ = part == 0 ? hi : (_Float16)(v - (float)hi);
+                                    }
             return;
         }
         if (conv_ad(c)) {
@@ -450,7 +482,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.sat = (L.sat_slot && precision == EAGLE_PREC_F32S) ? *L.sat_slot : nullptr;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
         const bool split = precision == EAGLE_PREC_F32S;
-        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((conv_ad_s2d(c) || conv_ad_s2t(c)) ? 2 : 1) || (split && !conv_ad_s2d(c) && c.cin % 48) || (split && conv_ad_s2d(c) && c.cin % 16) || (conv_ad_s2t(c) && !split))
+        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((conv_ad_s2d(c) || conv_ad_s2t(c)) ? 2 : 1) || (split && !conv_ad_s2d(c) && !conv_ad_m32(c) && c.cin % 48) || (split && (conv_ad_s2d(c) || conv_ad_m32(c)) && c.cin % 16) || (conv_ad_m32(c) && !split) || (conv_ad_s2t(c) && !split))
             fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32 (16 in the split family, stride 1 only), 2-byte / split output, pre_act none, post_act in {none, ReLU}");
         if (conv_ad_s2d(c)) a.nchunks = split ? 4 * c.cin / 16 : 4 * c.cin / 32;      // chunks of the space-to-depth image
         const int thh = conv_ad_rows(c);
@@ -460,7 +492,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 19) ? conv_ad_split_kernel48ring(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = conv_ad_m32(c) ? conv_ad_split32_kernel(conv_ad_wide(c), nres) : (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 19) ? conv_ad_split_kernel48ring(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         // workgroups per launch: one per item (the hardware hands a queued workgroup to whichever CU frees a slot: dynamic balance) rather than 512

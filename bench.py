@@ -182,6 +182,8 @@ def main():
                     help="take the WORLD_SIZE > 1 code path at world 1 (process group, library RCCL bootstrap, gather inside the timed region, max over ranks): "
                          "the one-GPU regression test of the process composition the driver runs at N = 8")
     a = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()                                  # a native crash (HIP / RCCL / the library) leaves a Python-level trace on stderr instead of nothing
     if a.cpu_baseline_only:
         cpu_baseline_child(a)
         return
@@ -226,13 +228,14 @@ def main():
     ys = weights.make_yolo_state_dict(a.detector, 0)
     if a.latency_only:
         fr = synth.clip(seed=0, n=max(a.distinct, 16), h=a.height, w=a.width)
-        modes = [("1stream", {"EAGLE_MULTI_STREAM": None}, {}), ("multi_stream", {"EAGLE_MULTI_STREAM": "1"}, {}),
-                 ("1stream+graph", {"EAGLE_MULTI_STREAM": None}, {"use_graph": 1}), ("multi_stream+graph", {"EAGLE_MULTI_STREAM": "1"}, {"use_graph": 1})]
-        print(json.dumps({"latency": latency_table(lib, weights, hs, ys, a, dev_index, fr, a.latency_calls, modes=modes)}), flush=True)
+        modes = [("1stream", {}, {"multi_stream": 0, "use_graph": 0}), ("multi_stream", {}, {"multi_stream": 1, "use_graph": 0}),
+                 ("1stream+graph", {}, {"multi_stream": 0, "use_graph": 1}), ("multi_stream+graph", {}, {"multi_stream": 1, "use_graph": 1})]
+        bs = tuple(int(x) for x in os.environ.get("LATENCY_BATCHES", "1,2,4,8").split(","))
+        print(json.dumps({"latency": latency_table(lib, weights, hs, ys, a, dev_index, fr, a.latency_calls, batches=bs, modes=modes)}), flush=True)
         return
     det_kw = {} if a.det_precision == "default" else {"det_precision": lib.PRECISIONS[a.det_precision] + 1}
     h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
-                   batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if a.graph else 0, **det_kw)
+                   batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if a.graph else lib.AUTO, **det_kw)
     inv_prec = {v: k for k, v in lib.PRECISIONS.items()}
     det_prec_name = inv_prec[h.cfg.det_precision - 1] if h.cfg.det_precision else a.precision
     weights.load_into(h, [hs, ys])
@@ -312,6 +315,17 @@ def main():
                            f"{os.environ.get('EAGLE_COPY_THREADS', '8')} worker threads, then DMA on a copy stream under the networks of the previous batch); "
                            "pinned = frames in eagle_host_alloc memory, DMA in place"}
         log(f"resident {r_res:.1f} frames/s, pinned source {r_pin:.1f} frames/s")
+
+    latency = None
+    if extras and a.latency_calls > 0:
+        # small-batch behaviour (north_star's API is Processor.process(frame); the reference's loop hands over one frame per iteration, cm.py:277):
+        # per-call wall time of eagle_process_frames at B = 1, 2, 4, 8 on the default handle (small-batch mode = the library's default for batch <= 8:
+        # hipGraph replay + HRNet's branches on their own streams), and the same handle with both switched off
+        fr = clip[:max(16, min(len(base), 64))]
+        latency = {"unit": "ms per eagle_process_frames call of B frames from pageable host memory (records back on the host)",
+                   "rows": latency_table(lib, weights, hs, ys, a, dev_index, fr, a.latency_calls,
+                                         modes=[("default (small-batch mode: hipGraph + branch streams)", {}, {}),
+                                                ("plain launches, one stream per network", {}, {"multi_stream": 0, "use_graph": 0})])}
 
     cadence = None
     if a.cadence > 0:
@@ -536,6 +550,8 @@ def main():
             res["parity_counters"] = parity
         if cfg3 is not None:
             res["cfg3"] = cfg3
+        if latency is not None:
+            res["latency"] = latency
         if cadence is not None:
             res["reference_cadence"] = cadence
         if cmc is not None:

@@ -20,7 +20,7 @@ from .pitch import INTERSECTION_TO_PITCH_POINTS
 class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
                  detector="n", det_imgsz=640, batch=8, precision="f32s", device=0, hrnet_state_dict=None,
-                 detector_state_dict=None, seed=0, use_graph=False, tracker=False, camera_motion=False, detector_precision=None,
+                 detector_state_dict=None, seed=0, use_graph=None, multi_stream=None, tracker=False, camera_motion=False, detector_precision=None,
                  reid=False, reid_state_dict=None, allow_saturation=False):
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
@@ -37,7 +37,9 @@ class CoordinateModel:
                                  det_imgsz=det_imgsz, batch=batch,
                                  precision=lib.PRECISIONS[precision],
                                  keypoint_conf=keypoint_conf, detector_conf=detector_conf,
-                                 detector_floor=min(detector_conf, 0.15), use_graph=int(use_graph),
+                                 detector_floor=min(detector_conf, 0.15),
+                                 use_graph=lib.AUTO if use_graph is None else int(bool(use_graph)),         # None: the library's small-batch rule (include/eagle.h EAGLE_SMALL_BATCH)
+                                 multi_stream=lib.AUTO if multi_stream is None else int(bool(multi_stream)),
                                  allow_saturation=int(allow_saturation), **dp)
         # the reference reads eagle/models/weights/*.pt|.pth (cm.py:55-59); none exist here -> seeded synthetic
         hs = hrnet_state_dict if hrnet_state_dict is not None else weights.make_hrnet_state_dict(seed)

@@ -17,6 +17,9 @@ ConvKernel conv_ad_split32_kernel(bool wide, int n_res)      // wide: two Cout g
     static const ConvKernel fn[2][3] = {
         {conv_split_ad32_kernel<1, 4, 0>, conv_split_ad32_kernel<1, 4, 1>, conv_split_ad32_kernel<1, 4, 2>},
         {conv_split_ad32_kernel<2, 2, 0>, conv_split_ad32_kernel<2, 2, 1>, conv_split_ad32_kernel<2, 2, 2>}};
+    // developer measurement (EAGLE_CONV_M32_RING=6): the weight ring five steps ahead instead of two, residual-free launches only (72 ring registers)
+    static const bool ring6 = getenv("EAGLE_CONV_M32_RING") && atoi(getenv("EAGLE_CONV_M32_RING")) == 6;
+    if (ring6 && n_res <= 0) return wide ? (ConvKernel)conv_split_ad32_kernel<2, 2, 0, 6> : (ConvKernel)conv_split_ad32_kernel<1, 4, 0, 6>;
     return fn[wide ? 1 : 0][n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
 }
 

@@ -1118,7 +1118,8 @@ int eagle_default_config(EagleConfig* cfg)
     cfg->det_variant = EAGLE_DET_N; cfg->det_imgsz = 640; cfg->batch = 8; cfg->precision = EAGLE_PREC_F32S;      // fp32-grade results by default (the reference computes in fp32)
     cfg->keypoint_conf = 0.3; cfg->detector_conf = 0.35; cfg->ransac_thresh = 5.0;
     cfg->detector_floor = 0.15f; cfg->nms_iou = 0.7f;
-    cfg->ransac_max_iters = 2000; cfg->lm_iters = 10; cfg->use_graph = 0;
+    cfg->ransac_max_iters = 2000; cfg->lm_iters = 10;
+    cfg->use_graph = EAGLE_AUTO; cfg->multi_stream = EAGLE_AUTO;      // small-batch mode (batch <= EAGLE_SMALL_BATCH): hipGraph replay + HRNet's branches on their own streams
     // "auto" (resolved by eagle_create from the `precision` the caller ends up with): next to split-family key-points the detector (1.4 % of the
     // FLOP with yolov8n) runs in the exact fp32 family — boxes, confidences, classes, the NMS order and therefore every detection-index id
     // (cm.py:598-627) equal the fp32 oracle's bit for bit; next to any other `precision` it runs in that same family
@@ -1130,6 +1131,15 @@ int eagle_resolve_config(EagleConfig* cfg)
 {
     if (!cfg) return EAGLE_E_INVALID;
     if (cfg->det_precision == EAGLE_DET_PREC_AUTO) cfg->det_precision = cfg->precision == EAGLE_PREC_F32S ? EAGLE_PREC_F32 + 1 : 0;
+    // Small-batch mode (round 5; the reference's caller hands over ONE frame per iteration, cm.py:277).  A step of <= EAGLE_SMALL_BATCH frames leaves most
+    // of the chip idle inside every launch (48->48 @135x240 is 116 workgroups per frame for 512 slots) and its 383 launches cost as much as its kernels:
+    // the network phase is replayed as ONE hipGraph and HRNet's branches (and the detector) run on their own streams so that the small launches of
+    // different branches fill the CUs together.  Measured on MI355X (default handle, per call incl. H2D and records back, bench.py `latency`): B = 1
+    // 13.9 -> 9.6 ms, B = 4 252 -> 344 frames/s, B = 8 395 -> 505 frames/s; at B = 50 the same switches measure nothing (DESIGN.md §4b xii), so larger
+    // batches keep one stream per network and plain launches.  EAGLE_MULTI_STREAM in the environment forces the branch streams on for any batch.
+    const bool small = cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH;
+    if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = small ? 1 : 0;
+    if (cfg->multi_stream == EAGLE_AUTO) cfg->multi_stream = (small || getenv("EAGLE_MULTI_STREAM") != nullptr) ? 1 : 0;
     return EAGLE_OK;
 }
 
@@ -1142,6 +1152,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32 && cfg->precision != EAGLE_PREC_F32S) fail(EAGLE_E_INVALID, "bad precision");
     if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
     if (cfg->det_precision < EAGLE_DET_PREC_AUTO || cfg->det_precision > EAGLE_PREC_F32S + 1) fail(EAGLE_E_INVALID, "bad detector precision");
+    if (cfg->use_graph < EAGLE_AUTO || cfg->use_graph > 1 || cfg->multi_stream < EAGLE_AUTO || cfg->multi_stream > 1) fail(EAGLE_E_INVALID, "use_graph / multi_stream: -1 (auto), 0 or 1");
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) fail(EAGLE_E_HIP, "device %d not present (%d visible)", cfg->device, ndev);
@@ -1156,7 +1167,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     for (auto& st : nh->s_br) HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_fork, hipEventDisableTiming));
     for (auto& e : nh->ev_join) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    nh->multi_stream = getenv("EAGLE_MULTI_STREAM") != nullptr;   // concurrent HRNet branches: measured slightly slower than one stream once the kernels fill the GPU
+    nh->multi_stream = nh->cfg.multi_stream != 0;         // concurrent HRNet branches: pays for small batches only (eagle_resolve_config)
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_pre, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&nh->ev_det, hipEventDisableTiming));
     HIP_CHECK(hipEventCreate(&nh->ev_t0));
@@ -1172,6 +1183,11 @@ void eagle_destroy(EagleHandle* h)
     if (h->tracker) eagle::tracker_destroy(h->tracker);
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
+    if (h->comm && h->rccl) {                               // the communicator of eagle_comm_init: released with the handle, before its streams go
+        typedef int (*fn_comm_destroy)(void*);
+        if (fn_comm_destroy cd = (fn_comm_destroy)dlsym(h->rccl, "ncclCommDestroy")) (void)cd(h->comm);
+        h->comm = nullptr;
+    }
     for (auto& sb : h->sb) {
         if (sb.gexec) (void)hipGraphExecDestroy(sb.gexec);
         if (sb.h_sat) (void)hipHostFree(sb.h_sat);       // (h_out lies inside it)

@@ -43,6 +43,8 @@ extern "C" {
                                   three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi) into an fp32 accumulator: the error of an fp32 summation in
                                   another order, at 3/16 of the fp32 MFMA's cost per product */
 
+#define EAGLE_AUTO (-1)          /* EagleConfig::use_graph / multi_stream: chosen from `batch` by eagle_create (eagle_resolve_config) */
+#define EAGLE_SMALL_BATCH 8      /* steps of at most this many frames run in small-batch mode (hipGraph replay + branch streams) unless the caller says otherwise */
 #define EAGLE_DET_PREC_AUTO (-1) /* EagleConfig::det_precision: chosen from `precision` by eagle_create */
 
 #define EAGLE_DET_N 0
@@ -68,7 +70,8 @@ typedef struct EagleConfig {
     float nms_iou;             /* 0.7   ultralytics default */
     int32_t ransac_max_iters;  /* 2000  cv2 default */
     int32_t lm_iters;          /* 10    cv2 default */
-    int32_t use_graph;         /* 1: capture the per-batch step into a hipGraph and replay it */
+    int32_t use_graph;         /* 1: capture the per-batch step into a hipGraph and replay it; 0: plain launches; EAGLE_AUTO (default): 1 when
+                                  batch <= EAGLE_SMALL_BATCH (the per-frame use of the reference's loop, cm.py:277), else 0 */
     int32_t det_precision;     /* 0: the detector runs in `precision`; EAGLE_PREC_* + 1: that family for the detector alone; EAGLE_DET_PREC_AUTO (what
                                   eagle_default_config sets; resolved by eagle_create): EAGLE_PREC_F32 + 1 when `precision` is EAGLE_PREC_F32S — key-points
                                   in the split family, the detector (1.4 % of the FLOP with yolov8n) in the exact fp32 family, so that boxes, confidences,
@@ -76,7 +79,10 @@ typedef struct EagleConfig {
                                   that takes the defaults and only sets precision = EAGLE_PREC_F16 gets BOTH networks in the fast family) */
     int32_t allow_saturation;  /* EAGLE_PREC_F32S: 0 (default): a call in which an activation store was clipped at +-4094 returns EAGLE_E_RANGE;
                                   1: it returns EAGLE_OK and only flags the frames (EagleFrameResult.pad[1]) and counts them (EagleTimings) */
-    int32_t reserved[5];
+    int32_t multi_stream;      /* 1: HRNet's branches on their own HIP streams inside a step; 0: one stream per network; EAGLE_AUTO (default): 1 when
+                                  batch <= EAGLE_SMALL_BATCH or EAGLE_MULTI_STREAM is set in the environment (at large batches every launch fills the
+                                  chip and the extra streams measure nothing) */
+    int32_t reserved[4];
 } EagleConfig;
 
 typedef struct EagleDet {      /* one row of boxes.xyxy/.conf/.cls after NMS (cm.py:569-572) + cm.py:598-627 */

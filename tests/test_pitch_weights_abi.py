@@ -101,6 +101,15 @@ def test_default_config_semantics_and_new_fields():
     assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32S)).det_precision == lib.PREC_F32 + 1
     assert lib.resolve_config(lib.default_config(precision=lib.PREC_F16, det_precision=lib.PREC_F32S + 1)).det_precision == lib.PREC_F32S + 1
     assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32S, det_precision=0)).det_precision == 0
+    # small-batch mode (round 5): use_graph / multi_stream default to "auto" and resolve from the batch
+    assert (c.use_graph, c.multi_stream) == (lib.AUTO, lib.AUTO)
+    os.environ.pop("EAGLE_MULTI_STREAM", None)
+    for B, want in ((1, 1), (lib.SMALL_BATCH, 1), (lib.SMALL_BATCH + 1, 0), (50, 0)):
+        r = lib.resolve_config(lib.default_config(batch=B))
+        assert (r.use_graph, r.multi_stream) == (want, want), B
+    r = lib.resolve_config(lib.default_config(batch=1, use_graph=0, multi_stream=0))
+    assert (r.use_graph, r.multi_stream) == (0, 0)
+    assert "EAGLE_SMALL_BATCH 8" in open(os.path.join(ROOT, "include", "eagle.h")).read()
     assert lib.default_config(allow_saturation=1).allow_saturation == 1
     assert issubclass(lib.EagleRangeError, lib.EagleError) and lib.E_RANGE == -8
     hdr = open(os.path.join(ROOT, "include", "eagle.h")).read()

@@ -184,9 +184,15 @@ def main():
     a = ap.parse_args()
     import faulthandler
     faulthandler.enable()                                  # a native crash (HIP / RCCL / the library) leaves a Python-level trace on stderr instead of nothing
-    if a.cpu_baseline_only:
+    # ONE JSON line on stdout, whatever the native libraries print: torch's bundled RCCL writes a five-line version banner to C stdout (block-buffered when
+    # stdout is a pipe, so it comes out at exit, BEHIND the JSON line — round 5's first multirank run was mis-parsed that way).  fd 1 is pointed at stderr
+    # for the life of the process; the result line goes to a private duplicate of the original stdout.
+    if a.cpu_baseline_only:                                # (the child of the default run: prints its own one-line JSON object for the parent)
         cpu_baseline_child(a)
         return
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,7 +237,7 @@ def main():
         modes = [("1stream", {}, {"multi_stream": 0, "use_graph": 0}), ("multi_stream", {}, {"multi_stream": 1, "use_graph": 0}),
                  ("1stream+graph", {}, {"multi_stream": 0, "use_graph": 1}), ("multi_stream+graph", {}, {"multi_stream": 1, "use_graph": 1})]
         bs = tuple(int(x) for x in os.environ.get("LATENCY_BATCHES", "1,2,4,8").split(","))
-        print(json.dumps({"latency": latency_table(lib, weights, hs, ys, a, dev_index, fr, a.latency_calls, batches=bs, modes=modes)}), flush=True)
+        os.write(result_fd, (json.dumps({"latency": latency_table(lib, weights, hs, ys, a, dev_index, fr, a.latency_calls, batches=bs, modes=modes)}) + "\n").encode())
         return
     det_kw = {} if a.det_precision == "default" else {"det_precision": lib.PRECISIONS[a.det_precision] + 1}
     h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
@@ -271,12 +277,17 @@ def main():
     sync()
     t0 = time.perf_counter()
     h.process(clip, out)                              # K steps of B frames, from pageable host memory (eagle_process_frames)
+    t_proc = time.perf_counter()
     if multi:
         allrec = shard.gather_records(out, n_local * world, rank, world, handle=h, transport=gather_used, out=gathered, force=True)
     else:
         allrec = out
+    t_gath = time.perf_counter()
     sync()
     dt = time.perf_counter() - t0
+    parts = {"process_ms": round((t_proc - t0) * 1e3, 2), "gather_ms": round((t_gath - t_proc) * 1e3, 2), "barrier_ms": round((t0 + dt - t_gath) * 1e3, 2)}
+    if multi:
+        log(f"rank {rank}: timed region parts {parts}")
     if multi:
         tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -511,7 +522,7 @@ def main():
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}", "input": "pageable host memory (eagle_process_frames)",
                        "keypoint_precision": a.precision, "detector_precision": det_prec_name,
-                       "gather": "none" if not multi else gather_used, "hip_graph": bool(a.graph), "cpu_binding_rank0": cpu_binding,
+                       "gather": "none" if not multi else gather_used, "hip_graph": bool(a.graph), "cpu_binding_rank0": cpu_binding, "timed_region_parts_rank0": parts,
                        "runtime": "torch-bundled ROCm (torch imported before libeagle_hip.so)" if multi else "/opt/rocm (torch-free process)"},
             "roofline": {"bound": "mfma", "kernel": f"{CONV_KERNEL[a.precision]} (the {n_conv // prof_steps} convolution launches per step of the key-point network's family)",
                          "achieved": round(achieved, 2), "peak": round(PEAK[a.precision], 1), "unit": "TFLOP/s",
@@ -564,7 +575,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -219,6 +219,7 @@ struct EagleHandle {
     uint8_t* ecc_prev = nullptr; int ecc_prev_h = 0, ecc_prev_w = 0; bool ecc_has_prev = false;
     // comm
     void* rccl = nullptr; void* comm = nullptr; int rank = 0, world = 1;
+    void* gather_buf = nullptr; size_t gather_cap = 0;      // device staging of eagle_gather (send | receive), grown on demand
 };
 
 namespace eagle {
@@ -1137,9 +1138,10 @@ int eagle_resolve_config(EagleConfig* cfg)
     // different branches fill the CUs together.  Measured on MI355X (default handle, per call incl. H2D and records back, bench.py `latency`): B = 1
     // 13.9 -> 9.6 ms, B = 4 252 -> 344 frames/s, B = 8 395 -> 505 frames/s; at B = 50 the same switches measure nothing (DESIGN.md §4b xii), so larger
     // batches keep one stream per network and plain launches.  EAGLE_MULTI_STREAM in the environment forces the branch streams on for any batch.
-    const bool small = cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH;
-    if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = small ? 1 : 0;
-    if (cfg->multi_stream == EAGLE_AUTO) cfg->multi_stream = (small || getenv("EAGLE_MULTI_STREAM") != nullptr) ? 1 : 0;
+    // Sweep on one box (profiles/r05c_latency_modes.txt; frames/s plain -> small-batch mode): B = 1 72 -> 105, 4 252 -> 344, 8 395 -> 505, 12 506 -> 571,
+    // 16 530 -> 599 (the branch streams alone; the graph adds nothing beyond B = 8), 25 658 -> 674 (graph replay of a 25-frame step: 455, it loses), 50 0.
+    if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = (cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH) ? 1 : 0;
+    if (cfg->multi_stream == EAGLE_AUTO) cfg->multi_stream = ((cfg->batch >= 1 && cfg->batch <= EAGLE_MULTI_STREAM_BATCH) || getenv("EAGLE_MULTI_STREAM") != nullptr) ? 1 : 0;
     return EAGLE_OK;
 }
 
@@ -1200,6 +1202,7 @@ void eagle_destroy(EagleHandle* h)
     for (auto& e : h->span_pool) (void)hipEventDestroy(e);
     h->hr.reset(); h->yo.reset(); h->misc.reset(); h->reid.reset();
     if (h->ecc_prev) (void)hipFree(h->ecc_prev);
+    if (h->gather_buf) (void)hipFree(h->gather_buf);
     if (h->reid_crops_h) (void)hipHostFree(h->reid_crops_h);
     if (h->reid_feats_h) (void)hipHostFree(h->reid_feats_h);
     if (h->clip_sat_h) (void)hipHostFree(h->clip_sat_h);
@@ -1850,15 +1853,19 @@ int eagle_gather(EagleHandle* h, const EagleFrameResult* local, int n_local, Eag
     HIP_CHECK(hipSetDevice(h->cfg.device));
     fn_allgather ag = (fn_allgather)dlsym(h->rccl, "ncclAllGather");
     if (!ag) fail(EAGLE_E_COMM, "ncclAllGather missing");
-    void *d_send = nullptr, *d_recv = nullptr;
-    HIP_CHECK(hipMalloc(&d_send, std::max<size_t>(bytes, 16)));
-    HIP_CHECK(hipMalloc(&d_recv, std::max<size_t>(bytes * h->world, 16)));
+    // device staging of the collective: kept with the handle and only ever grown (a hipMalloc / hipFree pair per call sat inside the bench's timed region)
+    const size_t need = std::max<size_t>(bytes * (size_t)(h->world + 1), 256);
+    if (h->gather_cap < need) {
+        if (h->gather_buf) { (void)hipFree(h->gather_buf); h->gather_buf = nullptr; h->gather_cap = 0; }
+        HIP_CHECK(hipMalloc(&h->gather_buf, need));
+        h->gather_cap = need;
+    }
+    void *d_send = h->gather_buf, *d_recv = (char*)h->gather_buf + bytes;
     HIP_CHECK(hipMemcpyAsync(d_send, local, bytes, hipMemcpyHostToDevice, h->s_main));
     const int rc = ag(d_send, d_recv, bytes, /*ncclChar*/ 0, h->comm, h->s_main);
-    if (rc) { (void)hipFree(d_send); (void)hipFree(d_recv); fail(EAGLE_E_COMM, "ncclAllGather failed: %d", rc); }
+    if (rc) fail(EAGLE_E_COMM, "ncclAllGather failed: %d", rc);
     HIP_CHECK(hipMemcpyAsync(all, d_recv, bytes * h->world, hipMemcpyDeviceToHost, h->s_main));
     HIP_CHECK(hipStreamSynchronize(h->s_main));
-    (void)hipFree(d_send); (void)hipFree(d_recv);
     API_END(h)
 }
 

@@ -44,7 +44,8 @@ extern "C" {
                                   another order, at 3/16 of the fp32 MFMA's cost per product */
 
 #define EAGLE_AUTO (-1)          /* EagleConfig::use_graph / multi_stream: chosen from `batch` by eagle_create (eagle_resolve_config) */
-#define EAGLE_SMALL_BATCH 8      /* steps of at most this many frames run in small-batch mode (hipGraph replay + branch streams) unless the caller says otherwise */
+#define EAGLE_SMALL_BATCH 8      /* steps of at most this many frames replay their network phase as a hipGraph unless the caller says otherwise */
+#define EAGLE_MULTI_STREAM_BATCH 16 /* ... and steps of at most this many run HRNet's branches on their own streams (measured: +13 % at 12 and 16 frames, +2 % at 25, nothing at 50) */
 #define EAGLE_DET_PREC_AUTO (-1) /* EagleConfig::det_precision: chosen from `precision` by eagle_create */
 
 #define EAGLE_DET_N 0
@@ -80,7 +81,7 @@ typedef struct EagleConfig {
     int32_t allow_saturation;  /* EAGLE_PREC_F32S: 0 (default): a call in which an activation store was clipped at +-4094 returns EAGLE_E_RANGE;
                                   1: it returns EAGLE_OK and only flags the frames (EagleFrameResult.pad[1]) and counts them (EagleTimings) */
     int32_t multi_stream;      /* 1: HRNet's branches on their own HIP streams inside a step; 0: one stream per network; EAGLE_AUTO (default): 1 when
-                                  batch <= EAGLE_SMALL_BATCH or EAGLE_MULTI_STREAM is set in the environment (at large batches every launch fills the
+                                  batch <= EAGLE_MULTI_STREAM_BATCH or EAGLE_MULTI_STREAM is set in the environment (at large batches every launch fills the
                                   chip and the extra streams measure nothing) */
     int32_t reserved[4];
 } EagleConfig;

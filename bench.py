@@ -161,7 +161,8 @@ def main():
                     help="family of the key-point network. f32s (default): split precision, fp32-grade; f16: the fast family; f32: the bit-exact family")
     ap.add_argument("--det-precision", default="default", choices=["default", "f16", "f32", "f32s"],
                     help="family of the detector. default: the library's (exact fp32 next to f32s key-points, otherwise the key-point family)")
-    ap.add_argument("--distinct", type=int, default=20, help="distinct synthetic frames generated (tiled to the clip)")
+    ap.add_argument("--distinct", type=int, default=200, help="distinct synthetic frames generated per rank (tiled to the clip): 200 since round 5 — the data-dependent stages "
+                    "(NMS candidate counts, RANSAC iteration counts, key-point dedup) see 200 different frames, and parity_counters compares all of them with the exact family")
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU restatement and print its JSON object")

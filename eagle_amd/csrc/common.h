@@ -89,9 +89,9 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
 // ---- other kernels ----------------------------------------------------------------------------------------
 struct LetterBox { int new_h, new_w, top, left, out_h, out_w; };
 LetterBox letterbox_geometry(int h, int w, int imgsz);
-// which: bit 0 = write the key-point tensor, bit 1 = write the detector tensor
+// which: bit 0 = write the key-point tensor, bit 1 = write the detector tensor; det_precision >= 0: the detector tensor's family when it differs from `precision`
 void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det,
-                       const LetterBox& lb, hipStream_t s, int which = 3);
+                       const LetterBox& lb, hipStream_t s, int which = 3, int det_precision = -1);
 struct FuseUp { TView z; };
 void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s, unsigned* sat = nullptr);   // sat: as ConvArgs::sat
 void maxpool5_launch(const TView& x, const TView& y, hipStream_t s);

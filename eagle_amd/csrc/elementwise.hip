@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_px(const TView& v, size_t pix, float r, fl
     }
 }
 
-template <typename T>
+template <typename T, typename TD = T>      // T: element type of the key-point tensor, TD: of the detector tensor (a mixed handle runs its two networks in two families)
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* bgr, int n, int h, int w, TView kp, TView det, LetterBox lb, int which)
 {
     const size_t fsz = (size_t)h * w * 3;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* bgr, int
             const int yy = dy - lb.top, xx = dx - lb.left;
             if (yy >= 0 && yy < lb.new_h && xx >= 0 && xx < lb.new_w) resize_px(src, h, w, lb.new_h, lb.new_w, yy, xx, rgb);
             else rgb[0] = rgb[1] = rgb[2] = 114;
-            store_px<T>(det, (size_t)f * det_px + r, (float)rgb[0] / 255.0f, (float)rgb[1] / 255.0f, (float)rgb[2] / 255.0f);
+            store_px<TD>(det, (size_t)f * det_px + r, (float)rgb[0] / 255.0f, (float)rgb[1] / 255.0f, (float)rgb[2] / 255.0f);
         }
     }
 }
@@ -122,12 +122,27 @@ LetterBox letterbox_geometry(int h, int w, int imgsz)
     return lb;
 }
 
+template <typename T>
+static void preprocess_launch_det(int det_precision, dim3 grid, hipStream_t s, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det, const LetterBox& lb, int which)
+{
+    if (det_precision == EAGLE_PREC_F16) hipLaunchKernelGGL((preprocess_kernel<T, _Float16>), grid, dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
+    else if (det_precision == EAGLE_PREC_F32S) hipLaunchKernelGGL((preprocess_kernel<T, SplitT>), grid, dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
+    else hipLaunchKernelGGL((preprocess_kernel<T, float>), grid, dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
+}
+
 void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det,
-                       const LetterBox& lb, hipStream_t s, int which)
+                       const LetterBox& lb, hipStream_t s, int which, int det_precision)
 {
     const size_t total = (size_t)n * (((which & 1) ? kp.h * kp.w : 0) + ((which & 2) ? det.h * det.w : 0));
     if (total == 0) return;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    if (det_precision >= 0 && det_precision != precision) {      // mixed handle: ONE launch writes both tensors, each in its network's format (round 5; two launches before)
+        if (precision == EAGLE_PREC_F16) preprocess_launch_det<_Float16>(det_precision, dim3(blocks), s, d_bgr, n, h, w, kp, det, lb, which);
+        else if (precision == EAGLE_PREC_F32S) preprocess_launch_det<SplitT>(det_precision, dim3(blocks), s, d_bgr, n, h, w, kp, det, lb, which);
+        else preprocess_launch_det<float>(det_precision, dim3(blocks), s, d_bgr, n, h, w, kp, det, lb, which);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (precision == EAGLE_PREC_F16) hipLaunchKernelGGL(preprocess_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
     else if (precision == EAGLE_PREC_F32S) hipLaunchKernelGGL(preprocess_kernel<SplitT>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);
     else hipLaunchKernelGGL(preprocess_kernel<float>, dim3(blocks), dim3(256), 0, s, d_bgr, n, h, w, kp, det, lb, which);

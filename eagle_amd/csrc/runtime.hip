@@ -773,9 +773,7 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     if (!(g_dbg_skip & 16))
         timed(h, "preprocess", (double)n_active * ((double)c.frame_h * c.frame_w * 3 + (540.0 * 960 + (double)h->lb.out_h * h->lb.out_w) * h->kp_in.c * esz), h->s_main,
               [&] {
-                  if (h->det_prec == h->prec) { preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main); return; }
-                  preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main, 1);        // mixed handle: one pass per tensor format
-                  preprocess_launch(h->det_prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main, 2);
+                  preprocess_launch(h->prec, d_src, n_active, c.frame_h, c.frame_w, h->kp_in, h->det_in, h->lb, h->s_main, 3, h->det_prec);      // one launch, each tensor in its network's format
               });
     const bool two = !h->prof;
     hipStream_t sd = two ? h->s_det : h->s_main;
@@ -810,7 +808,11 @@ static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_activ
         if (!sb.gexec || sb.g_src != d_src || sb.g_n != n_active) {
             if (sb.gexec) { (void)hipGraphExecDestroy(sb.gexec); sb.gexec = nullptr; }
             hipGraph_t g = nullptr;
-            HIP_CHECK(hipStreamBeginCapture(h->s_main, hipStreamCaptureModeGlobal));
+            // thread-local capture mode: only THIS thread is held to capture-safe calls while the capture is open (it makes none: the warm-up step above has
+            // set every function attribute and allocated the zero / trash pages).  The global mode made every hipMalloc / hipFree / synchronise of ANY other
+            // thread fail with "operation not permitted when stream is capturing" — a second handle on another host thread, which is how the concurrency
+            // tests and a multi-handle server run — and left this stream in a broken capture (round 5: six tests of the suite, once small batches captured by default)
+            HIP_CHECK(hipStreamBeginCapture(h->s_main, hipStreamCaptureModeThreadLocal));
             enqueue_compute(h, p, d_src, n_active);
             HIP_CHECK(hipStreamEndCapture(h->s_main, &g));
             HIP_CHECK(hipGraphInstantiate(&sb.gexec, g, nullptr, nullptr, 0));

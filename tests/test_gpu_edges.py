@@ -300,8 +300,11 @@ def test_bench_multirank_process_composition_with_nccl_group_and_library_rccl(ga
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    # ... and NOTHING else on stdout: torch's bundled RCCL prints a version banner through C stdio that used to land behind the JSON line (round 5)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[-2000:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["value"] > 0 and res["config"]["gather"] == gather, res["config"]
+    assert res["config"]["runtime"].startswith("torch-bundled") and set(res["config"]["timed_region_parts_rank0"]) == {"process_ms", "gather_ms", "barrier_ms"}
     assert "bootstrap failed" not in r.stderr, r.stderr[-3000:]
 
 

@@ -12,6 +12,14 @@ namespace eagle {
 #include "conv_kernels.inc"
 #include "conv_ad_split32.inc"
 
+ConvKernel conv_ad_split32_kernel_w64(bool wide, int n_res)      // the wave's two pixel blocks side by side: BN 192, tile 2 x 64 (variant 23) / BN 96, tile 4 x 64 (variant 24)
+{
+    static const ConvKernel fn[2][3] = {
+        {conv_split_ad32_kernel<1, 4, 0, 3, 2>, conv_split_ad32_kernel<1, 4, 1, 3, 2>, conv_split_ad32_kernel<1, 4, 2, 3, 2>},
+        {conv_split_ad32_kernel<2, 2, 0, 3, 2>, conv_split_ad32_kernel<2, 2, 1, 3, 2>, conv_split_ad32_kernel<2, 2, 2, 3, 2>}};
+    return fn[wide ? 1 : 0][n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
+}
+
 ConvKernel conv_ad_split32_kernel(bool wide, int n_res)      // wide: two Cout groups of 96 x two pixel groups (BN 192, tile 4 x 32; variant 21); else one x four (BN 96, tile 8 x 32; variant 22)
 {
     static const ConvKernel fn[2][3] = {

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <cstdarg>
 #include <cstring>
@@ -47,6 +48,25 @@ void ensure_max_dynamic_lds(const void* fn, int bytes)
 }
 
 static thread_local std::string g_create_error;
+// hipGraph capture against the rest of the process.  While ANY stream of the process is being captured, HIP refuses every operation that touches the legacy stream
+// (hipMemcpy, hipMemset, a null-stream launch: hipErrorStreamCaptureImplicit) in every thread — also with a thread-local capture of non-blocking streams.  Small
+// batches capture by default since round 5, and a second handle on another host thread (the concurrency tests; a multi-handle server) uploads weights or runs an
+// operator on the null stream whenever it likes.  So a capture is made exclusive: every C-ABI entry holds this mutex shared for its duration (outermost call only),
+// the capturing thread trades its shared hold for the exclusive one around Begin ... EndCapture + instantiate (a few milliseconds, once per (slot, frame count)).
+static std::shared_mutex g_capture_mutex;
+static thread_local std::shared_lock<std::shared_mutex>* t_api_lock = nullptr;
+struct ApiGuard {
+    std::shared_lock<std::shared_mutex> lk;
+    bool outer;
+    ApiGuard() : lk(g_capture_mutex, std::defer_lock), outer(t_api_lock == nullptr) { if (outer) { lk.lock(); t_api_lock = &lk; } }
+    ~ApiGuard() { if (outer) t_api_lock = nullptr; }
+};
+struct CaptureExclusive {       // inside an API call: shared -> exclusive -> shared again
+    std::shared_lock<std::shared_mutex>* al;
+    std::unique_lock<std::shared_mutex> ex;
+    CaptureExclusive() : al(t_api_lock), ex(g_capture_mutex, std::defer_lock) { if (al && al->owns_lock()) al->unlock(); ex.lock(); }
+    ~CaptureExclusive() { ex.unlock(); if (al) al->lock(); }
+};
 static int g_dbg_skip = 0;      // developer bisection (eagle_debug "skip"): 1 HRNet, 2 detector, 4 decode + NMS, 8 geometry kernel, 16 preprocess, 32 heat-map maxima, 64 fuse_sum / pool / upsample ops, 128 convolutions
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
@@ -808,6 +828,7 @@ static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_activ
         if (!sb.gexec || sb.g_src != d_src || sb.g_n != n_active) {
             if (sb.gexec) { (void)hipGraphExecDestroy(sb.gexec); sb.gexec = nullptr; }
             hipGraph_t g = nullptr;
+            CaptureExclusive only_this_thread_talks_to_hip;
             // thread-local capture mode: only THIS thread is held to capture-safe calls while the capture is open (it makes none: the warm-up step above has
             // set every function attribute and allocated the zero / trash pages).  The global mode made every hipMalloc / hipFree / synchronise of ANY other
             // thread fail with "operation not permitted when stream is capturing" — a second handle on another host thread, which is how the concurrency
@@ -1097,7 +1118,7 @@ static void finalize(EagleHandle* h)
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
-#define API_BEGIN try {
+#define API_BEGIN try { eagle::ApiGuard api_guard_;
 #define API_END(h)                                                       \
     }                                                                    \
     catch (const eagle::Err& e) { if (h) (h)->err = e.msg; else eagle::g_create_error = e.msg; return e.code; } \

@@ -204,9 +204,10 @@ def test_conv_split_a_direct(cin, cout, shape, res, post):
 
 
 @pytest.mark.parametrize("cin,cout", [(96, 96), (192, 192), (48, 192), (384, 384), (64, 96), (16, 192), (32, 288), (144, 96)])
-@pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (5, 17, 30), (1, 68, 120), (1, 1, 1), (2, 9, 33)])
+@pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (5, 17, 30), (1, 68, 120), (1, 1, 1), (2, 9, 33), (2, 34, 60), (1, 7, 65)])
 @pytest.mark.parametrize("res,post", [(True, 1), (False, 1), (False, 0), (2, 1)])
-def test_conv_split_a_direct_m32(cin, cout, shape, res, post, monkeypatch):
+@pytest.mark.parametrize("tile", ["rows", "wide64"])
+def test_conv_split_a_direct_m32(cin, cout, shape, res, post, tile, monkeypatch):
     """Round 5: the A-direct kernels of the split family on v_mfma_f32_32x32x16_f16 (conv_ad_split32.inc; variant 21: BN = 192, tile 4 x 32; variant 22:
     BN = 96, tile 8 x 32; wave tile 96 channels x 2 rows x 32 pixels), forced through EAGLE_CONV_FORCE, against the fp32 oracle: ragged maps, partial tiles in
     both directions (a 33-column map: one pixel in the second tile), a 1 x 1 map, several items per workgroup and Cout blocks, 0 / 1 / 2 residual operands, and
@@ -215,7 +216,9 @@ def test_conv_split_a_direct_m32(cin, cout, shape, res, post, monkeypatch):
     from oracle import prims as P
     if shape[1] * shape[2] > 4000 and (cin > 96 or not res):
         pytest.skip("large map: one representative case")
-    monkeypatch.setenv("EAGLE_CONV_FORCE", "16,12,21" if cout % 192 == 0 else "16,6,22")
+    # tile "rows": the wave's two 32-pixel blocks in two rows (variants 21 / 22: tiles 4 x 32 / 8 x 32); "wide64": side by side (variants 23 / 24: tiles 2 x 64 / 4 x 64)
+    v = (21 if cout % 192 == 0 else 22) + (2 if tile == "wide64" else 0)
+    monkeypatch.setenv("EAGLE_CONV_FORCE", f"16,{12 if cout % 192 == 0 else 6},{v}")
     n, h, w = shape
     x = _rand((n, h, w, cin), 51)
     wt = _rand((3, 3, cin, cout), 52, (2.0 / (cin * 9)) ** 0.5)
@@ -225,7 +228,7 @@ def test_conv_split_a_direct_m32(cin, cout, shape, res, post, monkeypatch):
     ref = P.conv2d(x, wt, b, stride=1, pre=0, r1=r1, r2=r2, post=post)
     got = lib.op_conv2d(x, wt, b, 1, 0, r1, r2, post, lib.PREC_F32S)
     err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
-    assert err < F32S_TOL, f"split A-direct 32x32x16 conv error {err}"
+    assert err < F32S_TOL, f"split A-direct 32x32x16 conv (variant {v}) error {err}"
 
 
 @pytest.mark.parametrize("shape", [(3, 37, 45), (1, 16, 16), (2, 135, 240)])

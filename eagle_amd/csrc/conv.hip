@@ -125,6 +125,12 @@ static const Inst* find_inst(int precision, const ConvConfig& c)
 }
 bool conv_supported(int precision, const ConvConfig& c) { return find_inst(precision, c) != nullptr; }
 
+// Default form of the split family's 3x3 stride-1 layers with Cout = 96 k (EAGLE_CONV_M32 overrides; 0 = the 16x16x32 A-direct forms of rounds 3 / 4).
+// 6 since round 5: the 32x32x16 kernels, 4 x 32 tiles for BN = 192 and 4 x 64 tiles for BN = 96 on maps wider than 32 columns — same box, three alternating
+// pairs through the whole pipeline: 750.0 / 751.0 / 753.4 -> 761.3 / 761.5 / 761.8 frames/s with the tile per map (mode 4; +1.4 %), 96->96 @68x120 208.5 -> 193.5 us.
+#ifndef EAGLE_CONV_M32_DEFAULT
+#define EAGLE_CONV_M32_DEFAULT 6
+#endif
 struct Tuned { int ks, s, cin, cout, wo, kc, nt, wx, variant; };
 static const Tuned g_tuned[] = {
 #include "conv_tuned.inc"
@@ -205,7 +211,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
         // round 5: the 32x32x16 form of the A-direct kernel (variants 21 - 24) for the 3x3 stride-1 layers with Cout = 96 k; any Cin = 16 k.  EAGLE_CONV_M32: 0 off,
         // 1 the 4 x 32 / 8 x 32 tiles (variants 21 / 22), 2 only BN = 192 (variant 21), 3 only BN = 96 (variant 22), 4: the tile per map — 2 x 64 / 4 x 64 (variants 23 / 24)
         // where the map is wider than 32 columns and its rows then divide without a larger remainder (34 x 60, 68 x 120), otherwise 21 / 22
-        static const int m32 = getenv("EAGLE_CONV_M32") ? atoi(getenv("EAGLE_CONV_M32")) : 0;
+        const int m32 = getenv("EAGLE_CONV_M32") ? atoi(getenv("EAGLE_CONV_M32")) : EAGLE_CONV_M32_DEFAULT;      // (read per call: the parity tests switch it)
         if (sad_on && m32 && plain_epilogue && ks == 3 && stride == 1 && cin_pad % 16 == 0 && cout_pad % 96 == 0) {
             ConvConfig q = c; q.kc = 16;
             if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 21; } else { q.nt = 6; q.variant = 22; }

@@ -184,11 +184,13 @@ def test_conv_split_variants(force, cin, cout, ks, stride, monkeypatch):
 @pytest.mark.parametrize("cin,cout", [(96, 96), (192, 192), (48, 192), (384, 384), (144, 96), (48, 48), (96, 48), (48, 144)])
 @pytest.mark.parametrize("shape", [(3, 37, 45), (2, 5, 70), (1, 16, 16), (5, 17, 30), (1, 68, 120)])
 @pytest.mark.parametrize("res,post", [(True, 1), (False, 1), (False, 0), (2, 1)])
-def test_conv_split_a_direct(cin, cout, shape, res, post):
-    """The A-direct kernels of the split family (conv_ad_split.inc; conv_choose picks them for 3x3 stride-1 layers with Cin = 48 k and
-    Cout = 96 k) against the fp32 oracle: ragged maps, several items per workgroup and Cout blocks, 0 / 1 / 2 residual operands."""
+def test_conv_split_a_direct(cin, cout, shape, res, post, monkeypatch):
+    """The 16x16x32 A-direct kernels of the split family (conv_ad_split.inc; until round 5 conv_choose's pick for 3x3 stride-1 layers with Cin = 48 k and
+    Cout = 96 k; since then behind EAGLE_CONV_M32=0, the 32x32x16 forms being the default: test_conv_split_a_direct_m32) against the fp32 oracle: ragged maps,
+    several items per workgroup and Cout blocks, 0 / 1 / 2 residual operands."""
     from eagle_amd import lib
     from oracle import prims as P
+    monkeypatch.setenv("EAGLE_CONV_M32", "0")
     if shape[1] * shape[2] > 4000 and (cin > 96 or not res):
         pytest.skip("large map: one representative case")
     n, h, w = shape

@@ -1,6 +1,7 @@
 // Bandwidth-bound kernels of the per-frame path: fused frame preprocess (K1), HRNet fuse = bilinear
 // align_corners upsample + N-way sum + ReLU (K4), SPPF max-pool / nearest x2 / concat-by-slice (K8), and the
 // per-channel first-maximum of sigmoid(logits) (K5).  All NHWC, 16-byte vector accesses per lane.
+#include <type_traits>
 #include "common.h"
 #include "dmath.h"
 
@@ -152,6 +153,9 @@ void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w,
 // ------------------------------------------------------------------------------------------------------------
 // vector helpers: VEC channels per thread (8 fp16 / 4 fp32)
 // ------------------------------------------------------------------------------------------------------------
+#ifndef EAGLE_FUSE_NT
+#define EAGLE_FUSE_NT 0      // 1: fuse_sum's split-family output stores non-temporal (developer measurement, round 5)
+#endif
 template <typename T> struct Vec;
 template <> struct Vec<_Float16> {
     static constexpr int N = 8;
@@ -173,6 +177,13 @@ template <> struct Vec<SplitT> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float s = __builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f); hi[i] = (_Float16)s; lo[i] = (_Float16)(s - (float)hi[i]); }
         *(half8*)((char*)p + e * 4) = hi; *((half8*)((char*)p + e * 4) + 1) = lo;
+    }
+    __device__ __forceinline__ void store_nt(void* p, size_t e) const      // non-temporal: an output nothing re-reads inside the launch (fuse_sum; EAGLE_FUSE_NT)
+    {
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float s = __builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f); hi[i] = (_Float16)s; lo[i] = (_Float16)(s - (float)hi[i]); }
+        __builtin_nontemporal_store(hi, (half8*)((char*)p + e * 4)); __builtin_nontemporal_store(lo, (half8*)((char*)p + e * 4) + 1);
     }
 };
 template <> struct Vec<float> {
@@ -268,7 +279,8 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a)
         if (a.relu)
 #pragma unroll
             for (int k = 0; k < VN; ++k) acc.v[k] = acc.v[k] > 0.f ? acc.v[k] : 0.f;
-        acc.store(a.y.p, (size_t)pix * a.y.cs + a.y.off + g * VN);
+        if constexpr (EAGLE_FUSE_NT && std::is_same<T, SplitT>::value) acc.store_nt(a.y.p, (size_t)pix * a.y.cs + a.y.off + g * VN);
+        else acc.store(a.y.p, (size_t)pix * a.y.cs + a.y.off + g * VN);
         if constexpr (__is_same(T, SplitT)) {              // (Vec<SplitT> holds 16 x the value: the format's range is |16 v| <= 65504)
             float m = 0.0f;
 #pragma unroll

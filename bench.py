@@ -166,8 +166,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU restatement and print its JSON object")
-    ap.add_argument("--graph", action="store_true", help="replay the network phase of every step as a hipGraph (N = 1: +0.3 % at batch 50; the multi-rank path does it by default)")
-    ap.add_argument("--no-graph", action="store_true", help="multi-rank path: plain launches instead of the default hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay the network phase of EVERY step as a hipGraph (the library's default does it inside calls of >= 3 steps)")
+    ap.add_argument("--no-graph", action="store_true", help="plain launches only")
     ap.add_argument("--all-layers", action="store_true", help="roofline_conv_layers lists every convolution layer shape instead of the ten heaviest")
     ap.add_argument("--no-extras", action="store_true", help="skip resident / host_sources / families / cfg3 / roofline_hbm (profiling runs)")
     ap.add_argument("--exact-frames", type=int, default=1000, help="frames of the fp32 exact-family run (0: skip)")
@@ -243,9 +243,10 @@ def main():
         return
     det_kw = {} if a.det_precision == "default" else {"det_precision": lib.PRECISIONS[a.det_precision] + 1}
     h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
-                   batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if (a.graph or (multi and not a.no_graph)) else lib.AUTO, **det_kw)
-    # (multi-rank path: the step is replayed as a captured hipGraph — BASELINE.json configs[4] names it, and on the PyTorch wheel's ROCm 7.0.2 runtime, which this
-    #  composition runs on, plain launches cost 2.3 % of the frame rate that the replay gives back: same box 739 -> 751 frames/s against 756 torch-free, profiles/r05e_*)
+                   batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if a.graph else 0 if a.no_graph else lib.AUTO, **det_kw)
+    # (auto at batch 50 = "replay the step as a hipGraph inside calls of >= 3 steps": the timed call is K steps, so N = 1 and the multi-rank path both replay — BASELINE.json
+    #  configs[4] names it; on the PyTorch wheel's ROCm 7.0.2 runtime, which the multi-rank composition runs on, plain launches cost 2.3 % that the replay gives back:
+    #  same box 739 -> 751 frames/s against 756 -> 760 torch-free, profiles/r05e_*)
     inv_prec = {v: k for k, v in lib.PRECISIONS.items()}
     det_prec_name = inv_prec[h.cfg.det_precision - 1] if h.cfg.det_precision else a.precision
     weights.load_into(h, [hs, ys])
@@ -526,7 +527,7 @@ def main():
             "config": {"workload": f"{n_local}-frame {a.width}x{a.height} synthetic clip per GPU, yolov8{a.detector}@{a.imgsz} + HRNet-W48 keypoints + RANSAC homography",
                        "frames_per_step": B, "frames_total": total_frames, "parallelism": f"frame-shard x{world}", "input": "pageable host memory (eagle_process_frames)",
                        "keypoint_precision": a.precision, "detector_precision": det_prec_name,
-                       "gather": "none" if not multi else gather_used, "hip_graph": bool(h.cfg.use_graph), "cpu_binding_rank0": cpu_binding, "timed_region_parts_rank0": parts,
+                       "gather": "none" if not multi else gather_used, "hip_graph": bool(h.cfg.use_graph == 1 or (h.cfg.use_graph == 2 and K >= 3)), "cpu_binding_rank0": cpu_binding, "timed_region_parts_rank0": parts,
                        "runtime": "torch-bundled ROCm (torch imported before libeagle_hip.so)" if multi else "/opt/rocm (torch-free process)"},
             "roofline": {"bound": "mfma", "kernel": f"{CONV_KERNEL[a.precision]} (the {n_conv // prof_steps} convolution launches per step of the key-point network's family)",
                          "achieved": round(achieved, 2), "peak": round(PEAK[a.precision], 1), "unit": "TFLOP/s",

@@ -205,6 +205,7 @@ struct EagleHandle {
     DetLevel levels[3];
     PostParams pp;
     bool warmed = false;
+    int call_steps = 0;                      // steps of the eagle_process_* call being executed (graph_on)
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> conv_ev;
@@ -815,11 +816,16 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));     // join
 }
 
+// use_graph: 1 = every step is replayed; 2 (what "auto" resolves to for batch > EAGLE_SMALL_BATCH) = only inside calls of at least three steps — there the graph launch of
+// step i + 1 hides behind step i on the GPU and saves the host the 383 launches (+0.3 ... 0.5 % at batch 50; on the PyTorch wheel's ROCm 7.0.2 runtime, whose launch path is
+// slower, +1.6 %), while a ONE-step call of a large batch pays the graph launch in full before anything runs (B = 25 per call: 658 -> 455 frames/s, profiles/r05c_latency_modes.txt)
+static bool graph_on(const EagleHandle* h) { return h->cfg.use_graph == 1 || (h->cfg.use_graph == 2 && h->call_steps >= 3); }
+
 static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_active)
 {
     const EagleConfig& c = h->cfg;
     EagleHandle::StepBuf& sb = h->sb[p];
-    if (c.use_graph && !h->prof) {
+    if (graph_on(h) && !h->prof) {
         if (!h->warmed) {   // first call eager: lets every launcher set its function attributes outside a capture
             enqueue_compute(h, p, d_src, n_active);
             HIP_CHECK(hipStreamSynchronize(h->s_main));
@@ -893,6 +899,7 @@ static void run_pipeline(EagleHandle* h, int n, EagleFrameResult* out, Stage sta
     memset(&h->timings, 0, sizeof(h->timings));
     h->sat_events = 0; h->sat_frames = 0;
     if (n == 0) return;
+    h->call_steps = (n + B - 1) / B;
     HIP_CHECK(hipEventRecord(h->ev_t0, h->s_main));
     int prev_n = 0, prev_i = 0, k = 0;
     for (int i = 0; i < n; i += B, ++k) {
@@ -1163,7 +1170,7 @@ int eagle_resolve_config(EagleConfig* cfg)
     // batches keep one stream per network and plain launches.  EAGLE_MULTI_STREAM in the environment forces the branch streams on for any batch.
     // Sweep on one box (profiles/r05c_latency_modes.txt; frames/s plain -> small-batch mode): B = 1 72 -> 105, 4 252 -> 344, 8 395 -> 505, 12 506 -> 571,
     // 16 530 -> 599 (the branch streams alone; the graph adds nothing beyond B = 8), 25 658 -> 674 (graph replay of a 25-frame step: 455, it loses), 50 0.
-    if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = (cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH) ? 1 : 0;
+    if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = (cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH) ? 1 : 2;      // 2: replay only inside calls of >= 3 steps (graph_on)
     if (cfg->multi_stream == EAGLE_AUTO) cfg->multi_stream = ((cfg->batch >= 1 && cfg->batch <= EAGLE_MULTI_STREAM_BATCH) || getenv("EAGLE_MULTI_STREAM") != nullptr) ? 1 : 0;
     return EAGLE_OK;
 }
@@ -1177,7 +1184,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32 && cfg->precision != EAGLE_PREC_F32S) fail(EAGLE_E_INVALID, "bad precision");
     if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
     if (cfg->det_precision < EAGLE_DET_PREC_AUTO || cfg->det_precision > EAGLE_PREC_F32S + 1) fail(EAGLE_E_INVALID, "bad detector precision");
-    if (cfg->use_graph < EAGLE_AUTO || cfg->use_graph > 1 || cfg->multi_stream < EAGLE_AUTO || cfg->multi_stream > 1) fail(EAGLE_E_INVALID, "use_graph / multi_stream: -1 (auto), 0 or 1");
+    if (cfg->use_graph < EAGLE_AUTO || cfg->use_graph > 2 || cfg->multi_stream < EAGLE_AUTO || cfg->multi_stream > 1) fail(EAGLE_E_INVALID, "use_graph: -1 (auto), 0, 1 or 2; multi_stream: -1 (auto), 0 or 1");
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) fail(EAGLE_E_HIP, "device %d not present (%d visible)", cfg->device, ndev);
@@ -1285,7 +1292,8 @@ int eagle_process_device_frames(EagleHandle* h, const void* d_bgr, int n, EagleF
     if (!d_bgr || !out || n < 0) fail(EAGLE_E_INVALID, "bad argument");
     HIP_CHECK(hipSetDevice(h->cfg.device));
     const size_t fsz = (size_t)h->cfg.frame_h * h->cfg.frame_w * 3;
-    const bool direct = n <= h->cfg.batch || !h->cfg.use_graph;   // a multi-batch clip under graph replay goes through the
+    h->call_steps = (n + h->cfg.batch - 1) / h->cfg.batch;
+    const bool direct = n <= h->cfg.batch || !graph_on(h);        // a multi-batch clip under graph replay goes through the
     run_pipeline(h, n, out, [&](int p, int i, int na) -> const uint8_t* {   // stable staging pointer of its parity
         const uint8_t* src = (const uint8_t*)d_bgr + (size_t)i * fsz;
         if (direct) return src;

@@ -794,12 +794,12 @@ def test_small_batch_mode_records_equal_the_large_batch_handles(state_dicts, fra
     from eagle_amd.coordinate_model import CoordinateModel
     hs, ys = state_dicts
     big = CoordinateModel(batch=17, hrnet_state_dict=hs, detector_state_dict=ys)
-    assert (big.handle.cfg.use_graph, big.handle.cfg.multi_stream) == (0, 0)
+    assert (big.handle.cfg.use_graph, big.handle.cfg.multi_stream) == (2, 0)          # 2: graph replay only inside calls of >= 3 steps; this call is one step: plain launches
     ref = big.process_records(frames)
     big.handle.close()
     for B in (1, 2, 4, 8, 12):
         m = CoordinateModel(batch=B, hrnet_state_dict=hs, detector_state_dict=ys)
-        assert (m.handle.cfg.use_graph, m.handle.cfg.multi_stream) == ((1, 1) if B <= 8 else (0, 1)), B
+        assert (m.handle.cfg.use_graph, m.handle.cfg.multi_stream) == ((1, 1) if B <= 8 else (2, 1)), B
         got = m.process_records(frames)                     # 5 frames: ragged last step at B = 2, 4, 8 (another graph instance)
         again = m.process_records(frames[:1])               # a second call with another frame count on the same handle
         m.handle.close()
@@ -809,6 +809,12 @@ def test_small_batch_mode_records_equal_the_large_batch_handles(state_dicts, fra
     assert (p.handle.cfg.use_graph, p.handle.cfg.multi_stream) == (0, 0)
     assert p.process_records(frames).tobytes() == ref.tobytes()
     p.handle.close()
+    # use_graph = 2 on a call of three steps (5 frames through batch 2: 2 + 2 + 1 — replayed, with a re-capture for the ragged last step) and of one step (plain launches)
+    q = lib.Handle(batch=2, use_graph=2, multi_stream=0)
+    from eagle_amd import weights
+    weights.load_into(q, [hs, ys])
+    assert q.process(frames).tobytes() == ref.tobytes() and q.process(frames[:2]).tobytes() == ref[:2].tobytes()
+    q.close()
 
 
 # ---- the fp16 (fast) family on trial against the fp32 oracle (NOT its own fp16-emulating oracle) --------------------------------------------------

@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) time the CPU restatement and print its JSON object")
-    ap.add_argument("--graph", action="store_true", help="replay the network phase of EVERY step as a hipGraph (the library's default does it inside calls of >= 3 steps)")
+    ap.add_argument("--graph", action="store_true", help="replay the network phase of every step as a hipGraph (the multi-rank path does it by default inside calls of >= 3 steps)")
     ap.add_argument("--no-graph", action="store_true", help="plain launches only")
     ap.add_argument("--all-layers", action="store_true", help="roofline_conv_layers lists every convolution layer shape instead of the ten heaviest")
     ap.add_argument("--no-extras", action="store_true", help="skip resident / host_sources / families / cfg3 / roofline_hbm (profiling runs)")
@@ -243,10 +243,10 @@ def main():
         return
     det_kw = {} if a.det_precision == "default" else {"det_precision": lib.PRECISIONS[a.det_precision] + 1}
     h = lib.Handle(device=dev_index, frame_h=a.height, frame_w=a.width, det_variant=a.detector, det_imgsz=a.imgsz,
-                   batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if a.graph else 0 if a.no_graph else lib.AUTO, **det_kw)
-    # (auto at batch 50 = "replay the step as a hipGraph inside calls of >= 3 steps": the timed call is K steps, so N = 1 and the multi-rank path both replay — BASELINE.json
-    #  configs[4] names it; on the PyTorch wheel's ROCm 7.0.2 runtime, which the multi-rank composition runs on, plain launches cost 2.3 % that the replay gives back:
-    #  same box 739 -> 751 frames/s against 756 -> 760 torch-free, profiles/r05e_*)
+                   batch=B, precision=lib.PRECISIONS[a.precision], use_graph=1 if a.graph else 0 if a.no_graph else (2 if multi else lib.AUTO), **det_kw)
+    # (multi-rank path: use_graph = 2, the step replayed as a captured hipGraph inside calls of >= 3 steps — BASELINE.json configs[4] names it, and on the PyTorch wheel's ROCm 7.0.2
+    #  runtime, which this composition runs on, plain launches cost 2.3 % of the frame rate that the replay gives back: same box 739 -> 751 frames/s against 756 torch-free, where the
+    #  replay measures nothing either way (765.3 against 766.1), profiles/r05e_*, r05pq_*.  The captures happen in the warm-up steps when --warmup >= 3.)
     inv_prec = {v: k for k, v in lib.PRECISIONS.items()}
     det_prec_name = inv_prec[h.cfg.det_precision - 1] if h.cfg.det_precision else a.precision
     weights.load_into(h, [hs, ys])

@@ -816,9 +816,11 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
     if (two) HIP_CHECK(hipStreamWaitEvent(h->s_main, h->ev_det, 0));     // join
 }
 
-// use_graph: 1 = every step is replayed; 2 (what "auto" resolves to for batch > EAGLE_SMALL_BATCH) = only inside calls of at least three steps — there the graph launch of
-// step i + 1 hides behind step i on the GPU and saves the host the 383 launches (+0.3 ... 0.5 % at batch 50; on the PyTorch wheel's ROCm 7.0.2 runtime, whose launch path is
-// slower, +1.6 %), while a ONE-step call of a large batch pays the graph launch in full before anything runs (B = 25 per call: 658 -> 455 frames/s, profiles/r05c_latency_modes.txt)
+// use_graph: 1 = every step is replayed; 2 = only inside calls of at least three steps — there the graph launch of step i + 1 hides behind step i on the GPU and saves the host
+// the 383 launches, while a ONE-step call of a large batch pays the graph launch in full before anything runs (B = 25 per call: 658 -> 455 frames/s,
+// profiles/r05c_latency_modes.txt).  Measured at batch 50, 20 steps: nothing on /opt/rocm's runtime (765.3 against 766.1 frames/s), +1.6 % on the PyTorch wheel's ROCm 7.0.2 runtime,
+// whose launch path is slower (739 -> 751): bench.py asks for 2 in its multi-rank path; "auto" stays at plain launches for batch > EAGLE_SMALL_BATCH (a capture costs ~80 ms per
+// (slot, frame count), which a short first call would pay inside its own latency)
 static bool graph_on(const EagleHandle* h) { return h->cfg.use_graph == 1 || (h->cfg.use_graph == 2 && h->call_steps >= 3); }
 
 static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_active)
@@ -1170,7 +1172,7 @@ int eagle_resolve_config(EagleConfig* cfg)
     // batches keep one stream per network and plain launches.  EAGLE_MULTI_STREAM in the environment forces the branch streams on for any batch.
     // Sweep on one box (profiles/r05c_latency_modes.txt; frames/s plain -> small-batch mode): B = 1 72 -> 105, 4 252 -> 344, 8 395 -> 505, 12 506 -> 571,
     // 16 530 -> 599 (the branch streams alone; the graph adds nothing beyond B = 8), 25 658 -> 674 (graph replay of a 25-frame step: 455, it loses), 50 0.
-    if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = (cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH) ? 1 : 2;      // 2: replay only inside calls of >= 3 steps (graph_on)
+    if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = (cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH) ? 1 : 0;      // (2 = replay only inside calls of >= 3 steps: on request)
     if (cfg->multi_stream == EAGLE_AUTO) cfg->multi_stream = ((cfg->batch >= 1 && cfg->batch <= EAGLE_MULTI_STREAM_BATCH) || getenv("EAGLE_MULTI_STREAM") != nullptr) ? 1 : 0;
     return EAGLE_OK;
 }

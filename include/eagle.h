@@ -73,7 +73,8 @@ typedef struct EagleConfig {
     int32_t lm_iters;          /* 10    cv2 default */
     int32_t use_graph;         /* 1: capture the per-batch step into a hipGraph and replay it; 0: plain launches; 2: replay only inside calls of at least three
                                   steps (the graph launch of a step then hides behind the previous step on the GPU; a one-step call of a large batch would pay it
-                                  up front); EAGLE_AUTO (default): 1 when batch <= EAGLE_SMALL_BATCH (the per-frame use of the reference's loop, cm.py:277), else 2 */
+                                  up front; a capture costs ~80 ms per (slot, frame count), once); EAGLE_AUTO (default): 1 when batch <= EAGLE_SMALL_BATCH (the per-frame
+                                  use of the reference's loop, cm.py:277), else 0 */
     int32_t det_precision;     /* 0: the detector runs in `precision`; EAGLE_PREC_* + 1: that family for the detector alone; EAGLE_DET_PREC_AUTO (what
                                   eagle_default_config sets; resolved by eagle_create): EAGLE_PREC_F32 + 1 when `precision` is EAGLE_PREC_F32S — key-points
                                   in the split family, the detector (1.4 % of the FLOP with yolov8n) in the exact fp32 family, so that boxes, confidences,

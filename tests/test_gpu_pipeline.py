@@ -794,12 +794,12 @@ def test_small_batch_mode_records_equal_the_large_batch_handles(state_dicts, fra
     from eagle_amd.coordinate_model import CoordinateModel
     hs, ys = state_dicts
     big = CoordinateModel(batch=17, hrnet_state_dict=hs, detector_state_dict=ys)
-    assert (big.handle.cfg.use_graph, big.handle.cfg.multi_stream) == (2, 0)          # 2: graph replay only inside calls of >= 3 steps; this call is one step: plain launches
+    assert (big.handle.cfg.use_graph, big.handle.cfg.multi_stream) == (0, 0)
     ref = big.process_records(frames)
     big.handle.close()
     for B in (1, 2, 4, 8, 12):
         m = CoordinateModel(batch=B, hrnet_state_dict=hs, detector_state_dict=ys)
-        assert (m.handle.cfg.use_graph, m.handle.cfg.multi_stream) == ((1, 1) if B <= 8 else (2, 1)), B
+        assert (m.handle.cfg.use_graph, m.handle.cfg.multi_stream) == ((1, 1) if B <= 8 else (0, 1)), B
         got = m.process_records(frames)                     # 5 frames: ragged last step at B = 2, 4, 8 (another graph instance)
         again = m.process_records(frames[:1])               # a second call with another frame count on the same handle
         m.handle.close()

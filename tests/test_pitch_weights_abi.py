@@ -104,8 +104,7 @@ def test_default_config_semantics_and_new_fields():
     # small-batch mode (round 5): use_graph / multi_stream default to "auto" and resolve from the batch
     assert (c.use_graph, c.multi_stream) == (lib.AUTO, lib.AUTO)
     os.environ.pop("EAGLE_MULTI_STREAM", None)
-    # (use_graph 2 = replay only inside calls of >= 3 steps: what "auto" means for batch > EAGLE_SMALL_BATCH)
-    for B, want in ((1, (1, 1)), (lib.SMALL_BATCH, (1, 1)), (lib.SMALL_BATCH + 1, (2, 1)), (lib.MULTI_STREAM_BATCH, (2, 1)), (lib.MULTI_STREAM_BATCH + 1, (2, 0)), (50, (2, 0))):
+    for B, want in ((1, (1, 1)), (lib.SMALL_BATCH, (1, 1)), (lib.SMALL_BATCH + 1, (0, 1)), (lib.MULTI_STREAM_BATCH, (0, 1)), (lib.MULTI_STREAM_BATCH + 1, (0, 0)), (50, (0, 0))):
         r = lib.resolve_config(lib.default_config(batch=B))
         assert (r.use_graph, r.multi_stream) == want, B
     r = lib.resolve_config(lib.default_config(batch=1, use_graph=0, multi_stream=0))

@@ -148,32 +148,66 @@ __global__ __launch_bounds__(NMS_T) void nms_kernel(NmsArgs a)
     const int* cls = a.sc.cls + (size_t)f * A;
     if (tid == 0) s_nk = 0;
     __syncthreads();
-    // greedy suppression in sorted order (torchvision.ops.nms on boxes + cls*7680, IoU > thr suppresses)
-    for (int i = 0; i < cnt; ++i) {
-        if (dead[i]) continue;                                 // uniform: everyone reads the same byte
-        const int nk = s_nk;
-        if (nk >= EAGLE_MAX_DET) break;
-        const int ai = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
-        const float offi = (float)cls[ai] * 7680.0f;
-        const float4 bi4 = *(const float4*)(boxes + (size_t)ai * 4);
-        const float bx1 = bi4.x + offi, by1 = bi4.y + offi, bx2 = bi4.z + offi, by2 = bi4.w + offi;
-        const float areai = (bx2 - bx1) * (by2 - by1);
-        for (int j = i + 1 + tid; j < cnt; j += NMS_T) {
-            if (dead[j]) continue;
-            const int aj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
-            const float offj = (float)cls[aj] * 7680.0f;
-            const float4 bj4 = *(const float4*)(boxes + (size_t)aj * 4);
-            const float cx1 = bj4.x + offj, cy1 = bj4.y + offj, cx2 = bj4.z + offj, cy2 = bj4.w + offj;
-            const float areaj = (cx2 - cx1) * (cy2 - cy1);
-            const float xx1 = fmaxf(bx1, cx1), yy1 = fmaxf(by1, cy1), xx2 = fminf(bx2, cx2), yy2 = fminf(by2, cy2);
-            const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
-            const float inter = iw * ih;
-            const float ovr = inter / (areai + areaj - inter);
-            if (ovr > a.pp.nms_iou) dead[j] = 1;
+    // greedy suppression in sorted order (torchvision.ops.nms on boxes + cls*7680, IoU > thr suppresses), 64 candidates at a time (round 5; until then: two workgroup
+    // barriers per KEPT box, 226 us per launch).  (1) ONE wave walks the block sequentially with no barrier: lane l holds candidate b0 + l, the 64-bit `alive` mask is
+    // uniform, the box of the next alive candidate is broadcast with a cross-lane read and every later lane tests itself against it (one ballot per kept box).  (2) after
+    // ONE barrier all threads test the candidates behind the block against the block's kept boxes (staged in LDS).  The same comparisons with the same fp32 expression as
+    // the one-box-at-a-time loop, in an order that cannot change their outcome: a candidate dies iff some EARLIER KEPT box overlaps it, and whether a box is kept is decided
+    // before anything behind it is looked at.  The 300-box cap (ultralytics max_det) stops the walk at the first alive candidate that would be number 301, as before.
+    __shared__ float s_kb[64][5];                              // kept boxes of the block: x1, y1, x2, y2 (class offset added), area
+    __shared__ int s_kc, s_stop;
+    if (tid == 0) s_stop = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < cnt; b0 += 64) {
+        if (tid < 64) {
+            const int j = b0 + tid;
+            const bool valid = j < cnt && !dead[j];
+            float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f;
+            if (valid) {
+                const int aj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
+                const float offj = (float)cls[aj] * 7680.0f;
+                const float4 bj4 = *(const float4*)(boxes + (size_t)aj * 4);
+                x1 = bj4.x + offj; y1 = bj4.y + offj; x2 = bj4.z + offj; y2 = bj4.w + offj;
+                area = (x2 - x1) * (y2 - y1);
+            }
+            unsigned long long alive = __ballot(valid);
+            int nk = s_nk, kc = 0, stop = 0;
+            while (alive) {
+                const int i = __builtin_ctzll(alive);
+                if (nk >= EAGLE_MAX_DET) { stop = 1; break; }
+                alive &= alive - 1;                            // box b0 + i is kept
+                const float bx1 = __shfl(x1, i), by1 = __shfl(y1, i), bx2 = __shfl(x2, i), by2 = __shfl(y2, i), areai = __shfl(area, i);
+                if (tid == i) { kept[nk] = b0 + i; s_kb[kc][0] = bx1; s_kb[kc][1] = by1; s_kb[kc][2] = bx2; s_kb[kc][3] = by2; s_kb[kc][4] = areai; }
+                ++nk; ++kc;
+                const float xx1 = fmaxf(bx1, x1), yy1 = fmaxf(by1, y1), xx2 = fminf(bx2, x2), yy2 = fminf(by2, y2);
+                const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+                const float inter = iw * ih;
+                const float ovr = inter / (areai + area - inter);
+                alive &= ~__ballot(tid > i && ovr > a.pp.nms_iou);
+            }
+            if (tid == 0) { s_nk = nk; s_kc = kc; s_stop = stop; }
         }
         __syncthreads();
-        if (tid == 0) { kept[nk] = i; s_nk = nk + 1; }
-        __syncthreads();
+        if (s_stop) break;
+        const int kc = s_kc;
+        if (kc > 0)
+            for (int j = b0 + 64 + tid; j < cnt; j += NMS_T) {
+                if (dead[j]) continue;
+                const int aj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
+                const float offj = (float)cls[aj] * 7680.0f;
+                const float4 bj4 = *(const float4*)(boxes + (size_t)aj * 4);
+                const float cx1 = bj4.x + offj, cy1 = bj4.y + offj, cx2 = bj4.z + offj, cy2 = bj4.w + offj;
+                const float areaj = (cx2 - cx1) * (cy2 - cy1);
+                for (int k = 0; k < kc; ++k) {
+                    const float bx1 = s_kb[k][0], by1 = s_kb[k][1], bx2 = s_kb[k][2], by2 = s_kb[k][3], areai = s_kb[k][4];
+                    const float xx1 = fmaxf(bx1, cx1), yy1 = fmaxf(by1, cy1), xx2 = fminf(bx2, cx2), yy2 = fminf(by2, cy2);
+                    const float iw = fmaxf(0.f, xx2 - xx1), ih = fmaxf(0.f, yy2 - yy1);
+                    const float inter = iw * ih;
+                    const float ovr = inter / (areai + areaj - inter);
+                    if (ovr > a.pp.nms_iou) { dead[j] = 1; break; }
+                }
+            }
+        __syncthreads();                                       // dead[] of the next block is final; s_kb may be rewritten
     }
     __syncthreads();
     const int K = s_nk;
@@ -225,8 +259,8 @@ void nms_launch(const DetScratch& sc, int n, const PostParams& pp, EagleFrameRes
     while (cap < sc.A) cap <<= 1;
     a.cap = cap;
     const size_t lds = (size_t)cap * 9;
-    ensure_max_dynamic_lds((const void*)nms_kernel, 160 * 1024 - 2048);
-    if (lds > 160 * 1024 - 2048) fail(EAGLE_E_INVALID, "too many anchors for the NMS workgroup: %d", sc.A);
+    ensure_max_dynamic_lds((const void*)nms_kernel, 160 * 1024 - 4096);
+    if (lds > 160 * 1024 - 4096) fail(EAGLE_E_INVALID, "too many anchors for the NMS workgroup: %d", sc.A);
     hipLaunchKernelGGL(nms_kernel, dim3(n), dim3(NMS_T), lds, s, a);
     HIP_CHECK(hipGetLastError());
 }

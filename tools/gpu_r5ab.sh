@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: the Cout = 48 A-direct forms re-measured through the pipeline now that the stores are non-temporal: base (variant 18 generic 8 x 48 tiles) against EAGLE_CONV_KQ=12 / 13 (all
+# Round 5 (record; the "48NR=12" arm needs the one-line conv.hip change quoted in profiles/r05ab_*): the Cout = 48 A-direct forms re-measured through the pipeline now that the stores are non-temporal: base (variant 18 generic 8 x 48 tiles) against EAGLE_CONV_KQ=12 / 13 (all
 # 48->48 launches on the K-split / the 16 x 32 single-buffer form) and EAGLE_CONV_48NR=12 (K-split for the residual-free launches only), three alternating rounds.
 tag=${1:-r05ab}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O

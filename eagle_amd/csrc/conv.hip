@@ -32,13 +32,13 @@ static int f16_ni(int ks, int kc) { return (ks * ks * (kc / 8) + 3) / 4; }
 
 static int conv_pw(const ConvConfig& c) { return (c.variant == 3 || c.variant == 7) ? 2 : c.variant == 4 ? 1 : c.variant == 18 ? 6 : 4; }
 static bool conv_ws(const ConvConfig& c) { return c.variant == 6 || c.variant == 7; }
-static bool conv_ad_m32(const ConvConfig& c) { return c.variant >= 21 && c.variant <= 26; }      // split family on v_mfma_f32_32x32x16_f16 (conv_ad_split32.inc): 21 = BN 192, tile 4 x 32; 22 = BN 96, tile 8 x 32; 23 = BN 192, tile 2 x 64; 24 = BN 96, tile 4 x 64
+static bool conv_ad_m32(const ConvConfig& c) { return c.variant >= 21 && c.variant <= 24; }      // split family on v_mfma_f32_32x32x16_f16 (conv_ad_split32.inc): 21 = BN 192, tile 4 x 32; 22 = BN 96, tile 8 x 32; 23 = BN 192, tile 2 x 64; 24 = BN 96, tile 4 x 64
 static int conv_ad_tw(const ConvConfig& c) { return (c.variant == 23 || c.variant == 24) ? 64 : 32; }      // output columns of an A-direct tile
 static bool conv_ad(const ConvConfig& c) { return (c.variant >= 8 && c.variant <= 15) || c.variant == 19 || conv_ad_m32(c); }
 static bool conv_ad_s2t(const ConvConfig& c) { return c.variant == 14 || c.variant == 15; }      // TRUE stride 2 on a column-plane halo (14: BN 192; 15: BN 96, K split over wave pairs)
 static bool conv_ad_s2d(const ConvConfig& c) { return c.variant == 10 || c.variant == 11; }      // stride 2 over the space-to-depth image (variants 14 / 15: true stride 2, the stride-1 weight image)
-static int conv_ad_rows(const ConvConfig& c) { return c.variant == 23 ? 2 : (c.variant == 8 || c.variant == 10 || c.variant == 21 || c.variant == 24 || c.variant == 25 || c.variant == 26 || conv_ad_s2t(c)) ? 4 : (c.variant == 13 || c.variant == 19) ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
-static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10 || c.variant == 14 || c.variant == 21 || c.variant == 23 || c.variant == 25 || c.variant == 26; }
+static int conv_ad_rows(const ConvConfig& c) { return c.variant == 23 ? 2 : (c.variant == 8 || c.variant == 10 || c.variant == 21 || c.variant == 24 || conv_ad_s2t(c)) ? 4 : (c.variant == 13 || c.variant == 19) ? 16 : 8; }      // output rows of an A-direct tile      // A-direct: 8 = 4 Cout groups x 1 pixel group (BN 192), 9 = 2 x 2 (BN 96); 10 / 11 = the same for stride 2
+static bool conv_ad_wide(const ConvConfig& c) { return c.variant == 8 || c.variant == 10 || c.variant == 14 || c.variant == 21 || c.variant == 23; }
 
 static size_t lds_bytes(int precision, const ConvConfig& c)
 {
@@ -55,8 +55,8 @@ static size_t lds_bytes(int precision, const ConvConfig& c)
         return conv_ws(c) ? operands + strips + 16 : std::max(operands + 16, strips);
     }
     if (precision == EAGLE_PREC_F32S && conv_ad_m32(c)) {  // 80-byte halo records, two-deep ring, strips of 32 pixels x 32 channels x 4 bytes
-        const int slabs = (((conv_ad_rows(c) + 2) * (conv_ad_tw(c) + 2) * (c.variant == 26 ? 144 : 80) + 1023) / 1024 + 3) / 4 * 4;      // variant 26: records of two chunks
-        return (size_t)(c.variant == 25 ? 3 : 2) * slabs * 1024 + 4 * 32 * 128;       // strips: 128-byte records, units swizzled by the pixel; variant 25: three halo slots
+        const int slabs = (((conv_ad_rows(c) + 2) * (conv_ad_tw(c) + 2) * 80 + 1023) / 1024 + 3) / 4 * 4;
+        return (size_t)2 * slabs * 1024 + 4 * 32 * 128;       // strips: 128-byte records, units swizzled by the pixel
     }
     if (precision == EAGLE_PREC_F32S && conv_ad(c)) {      // same halo ring as the fp16 kernel (16 logical channels = the 96-byte record), strips of 16 pixels x 48 channels x 4 bytes
         const int hpix = conv_ad_s2t(c) ? (2 * conv_ad_rows(c) + 1) * 66 : (conv_ad_rows(c) + 2) * 34;      // variants 14 / 15: 9 rows x (33 even + 33 odd columns)
@@ -101,11 +101,7 @@ static const Inst g_ad_inst[] = {
     // split family, stride 1, on v_mfma_f32_32x32x16_f16 (round 5, conv_ad_split32.inc): BN = 192 (variant 21) / BN = 96 (variant 22)
     {EAGLE_PREC_F32S, 3, 1, 16, 12, 21, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 22, nullptr},
     // ... with the wave's two pixel blocks side by side (tiles 2 x 64 / 4 x 64: 34- and 68-row maps without a row remainder): variants 23 / 24
-    {EAGLE_PREC_F32S, 3, 1, 16, 12, 23, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 24, nullptr},
-    // ... BN = 192, tile 4 x 32, three halo slots: the halo requests of two chunks issued together at every second chunk (variant 25)
-    {EAGLE_PREC_F32S, 3, 1, 16, 12, 25, nullptr},
-    // ... BN = 192, tile 4 x 32, the halo of two chunks per request = whole 128-byte lines (Cin = 32 k; variant 26)
-    {EAGLE_PREC_F32S, 3, 1, 16, 12, 26, nullptr}};
+    {EAGLE_PREC_F32S, 3, 1, 16, 12, 23, nullptr}, {EAGLE_PREC_F32S, 3, 1, 16, 6, 24, nullptr}};
 
 const Inst* conv_inst_part(int part, int* n)
 {
@@ -218,8 +214,6 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
             ConvConfig q = c; q.kc = 16;
             if (cout_pad % 192 == 0) { q.nt = 12; q.variant = 21; } else { q.nt = 6; q.variant = 22; }
             if (m32 == 4 && wo > 32) q.variant += 2;
-            if (m32 == 5) q.variant = q.variant == 21 ? 25 : (wo > 32 ? 24 : 22);      // 5: the three-slot halo ring for BN = 192, the 4 x 64 tile for BN = 96 on wide maps
-            if (m32 == 7) q.variant = q.variant == 21 ? (cin_pad % 32 == 0 ? 26 : 21) : (wo > 32 ? 24 : 22);      // 7: whole-line halo requests for BN = 192
             if (m32 == 6) q.variant = q.variant == 21 ? 21 : (wo > 32 ? 24 : 22);      // 6: 4 x 32 tiles for BN = 192 (2 x 64 measured 1.5 % slower on 34 x 60), 4 x 64 for BN = 96 on wide maps
             if (m32 >= 4 || (q.variant == 21 && m32 != 3) || (q.variant == 22 && m32 != 2)) return q;
         }
@@ -500,7 +494,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
     a.sat = (L.sat_slot && precision == EAGLE_PREC_F32S) ? *L.sat_slot : nullptr;
     if (conv_ad(c)) {                                       // A-direct: persistent over XCD-contiguous item ranges, two workgroups per CU
         const bool split = precision == EAGLE_PREC_F32S;
-        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((conv_ad_s2d(c) || conv_ad_s2t(c)) ? 2 : 1) || (split && !conv_ad_s2d(c) && !conv_ad_m32(c) && c.cin % 48) || (split && (conv_ad_s2d(c) || conv_ad_m32(c)) && c.cin % 16) || (conv_ad_m32(c) && !split) || (c.variant == 26 && c.cin % 32) || (conv_ad_s2t(c) && !split))
+        if (a.out_f32 || a.pre_act != 0 || a.post_act > 1 || L.am_slot || c.kc != (split ? 16 : 32) || c.ks != 3 || c.stride != ((conv_ad_s2d(c) || conv_ad_s2t(c)) ? 2 : 1) || (split && !conv_ad_s2d(c) && !conv_ad_m32(c) && c.cin % 48) || (split && (conv_ad_s2d(c) || conv_ad_m32(c)) && c.cin % 16) || (conv_ad_m32(c) && !split) || (conv_ad_s2t(c) && !split))
             fail(EAGLE_E_NOKERNEL, "A-direct conv needs 3x3, kc = 32 (16 in the split family, stride 1 only), 2-byte / split output, pre_act none, post_act in {none, ReLU}");
         if (conv_ad_s2d(c)) a.nchunks = split ? 4 * c.cin / 16 : 4 * c.cin / 32;      // chunks of the space-to-depth image
         const int thh = conv_ad_rows(c);
@@ -510,7 +504,7 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = conv_ad_m32(c) ? c.variant == 26 ? conv_ad_split32_kernel_k2(nres) : c.variant == 25 ? conv_ad_split32_kernel_h3(nres) : (conv_ad_tw(c) == 64 ? conv_ad_split32_kernel_w64(conv_ad_wide(c), nres) : conv_ad_split32_kernel(conv_ad_wide(c), nres)) : (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 19) ? conv_ad_split_kernel48ring(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        const ConvKernel fn = conv_ad_m32(c) ? (conv_ad_tw(c) == 64 ? conv_ad_split32_kernel_w64(conv_ad_wide(c), nres) : conv_ad_split32_kernel(conv_ad_wide(c), nres)) : (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 19) ? conv_ad_split_kernel48ring(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
         ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
         // workgroups per launch: one per item (the hardware hands a queued workgroup to whichever CU frees a slot: dynamic balance) rather than 512

@@ -12,18 +12,6 @@ namespace eagle {
 #include "conv_kernels.inc"
 #include "conv_ad_split32.inc"
 
-ConvKernel conv_ad_split32_kernel_h3(int n_res)      // BN 192, tile 4 x 32, THREE halo slots with the requests of two chunks issued together (variant 25)
-{
-    static const ConvKernel fn[3] = {conv_split_ad32_kernel<2, 2, 0, 3, 1, 3>, conv_split_ad32_kernel<2, 2, 1, 3, 1, 3>, conv_split_ad32_kernel<2, 2, 2, 3, 1, 3>};
-    return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
-}
-
-ConvKernel conv_ad_split32_kernel_k2(int n_res)      // BN 192, tile 4 x 32, the halo of two 16-channel chunks per request: whole 128-byte lines, 144-byte records (variant 26)
-{
-    static const ConvKernel fn[3] = {conv_split_ad32_kernel<2, 2, 0, 3, 1, 2, 2>, conv_split_ad32_kernel<2, 2, 1, 3, 1, 2, 2>, conv_split_ad32_kernel<2, 2, 2, 3, 1, 2, 2>};
-    return fn[n_res < 0 ? 0 : n_res > 2 ? 2 : n_res];
-}
-
 ConvKernel conv_ad_split32_kernel_w64(bool wide, int n_res)      // the wave's two pixel blocks side by side: BN 192, tile 2 x 64 (variant 23) / BN 96, tile 4 x 64 (variant 24)
 {
     static const ConvKernel fn[2][3] = {

@@ -45,7 +45,7 @@ int main(int argc, char** argv)
     hipMemset(db, 0, 1 << 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     static const int kcs[] = {64, 48, 32, 24, 16, 8}, nts[] = {12, 6, 4, 3, 2, 1};
-    static const int variants[] = {0, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 18, 19, 21, 22, 23, 24, 25, 26};
+    static const int variants[] = {0, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 18, 19, 21, 22, 23, 24};
     const char* only = getenv("TUNE_ONLY");          // "variant" or "variant,kc,nt": restrict the sweep
     for (auto& sh : shapes) {
         std::tie(ks, s, cin, cout, h, w, n) = sh;

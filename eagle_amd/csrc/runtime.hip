@@ -54,17 +54,30 @@ static thread_local std::string g_create_error;
 // operator on the null stream whenever it likes.  So a capture is made exclusive: every C-ABI entry holds this mutex shared for its duration (outermost call only),
 // the capturing thread trades its shared hold for the exclusive one around Begin ... EndCapture + instantiate (a few milliseconds, once per (slot, frame count)).
 static std::shared_mutex g_capture_mutex;
+static std::atomic<int> g_capture_waiting{0};      // threads queued for the exclusive hold: new API calls let them pass first (glibc's rwlock prefers readers; with
+                                                   // several handles making overlapping calls a capture could otherwise wait for ever)
 static thread_local std::shared_lock<std::shared_mutex>* t_api_lock = nullptr;
 struct ApiGuard {
     std::shared_lock<std::shared_mutex> lk;
     bool outer;
-    ApiGuard() : lk(g_capture_mutex, std::defer_lock), outer(t_api_lock == nullptr) { if (outer) { lk.lock(); t_api_lock = &lk; } }
+    ApiGuard() : lk(g_capture_mutex, std::defer_lock), outer(t_api_lock == nullptr)
+    {
+        if (!outer) return;
+        while (g_capture_waiting.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        lk.lock(); t_api_lock = &lk;
+    }
     ~ApiGuard() { if (outer) t_api_lock = nullptr; }
 };
 struct CaptureExclusive {       // inside an API call: shared -> exclusive -> shared again
     std::shared_lock<std::shared_mutex>* al;
     std::unique_lock<std::shared_mutex> ex;
-    CaptureExclusive() : al(t_api_lock), ex(g_capture_mutex, std::defer_lock) { if (al && al->owns_lock()) al->unlock(); ex.lock(); }
+    CaptureExclusive() : al(t_api_lock), ex(g_capture_mutex, std::defer_lock)
+    {
+        if (al && al->owns_lock()) al->unlock();
+        g_capture_waiting.fetch_add(1, std::memory_order_acq_rel);
+        ex.lock();
+        g_capture_waiting.fetch_sub(1, std::memory_order_acq_rel);
+    }
     ~CaptureExclusive() { ex.unlock(); if (al) al->lock(); }
 };
 static int g_dbg_skip = 0;      // developer bisection (eagle_debug "skip"): 1 HRNet, 2 detector, 4 decode + NMS, 8 geometry kernel, 16 preprocess, 32 heat-map maxima, 64 fuse_sum / pool / upsample ops, 128 convolutions

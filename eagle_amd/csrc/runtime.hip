@@ -1225,6 +1225,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
 
 void eagle_destroy(EagleHandle* h)
 {
+    eagle::ApiGuard not_during_a_capture;                  // hipDeviceSynchronize / hipFree below would invalidate a capture that another handle's thread has open
     if (h && h->clip.open) { (void)hipSetDevice(h->cfg.device); eagle::clip_close(h); }
     if (!h) return;
     if (h->tracker) eagle::tracker_destroy(h->tracker);

@@ -147,6 +147,52 @@ def latency_table(lib, weights, hs, ys, a, dev_index, frames, calls, batches=(1,
     return rows
 
 
+def self_launch(n, argv, print_only=False):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>`, the command the driver uses — relay rank 0's ONE JSON line to stdout, everything else to
+    stderr, and return the launcher's exit code.  Called before any GPU call and without importing the HIP library or torch in this process (a process that has
+    initialised the GPU must not be replaced, and need not be: the parent only waits)."""
+    import socket
+    with socket.socket() as sk:                            # a free rendezvous port on the loop-back interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + [x for x in argv if x != "--print-launch"]
+    if print_only:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for ln in p.stdout:                                    # rank 0 prints exactly one JSON line; anything else a native library wrote to stdout goes to stderr
+        t = ln.strip()
+        ok = False
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                ok = "metric" in json.loads(t)
+            except ValueError:
+                ok = False
+        if ok:
+            line = t
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc == 0 and line is None:
+        log("the ranks exited 0 but printed no result line")
+        rc = 1
+    if line is not None and rc == 0:
+        got = json.loads(line).get("n_gpus")
+        if got != n:                                       # cannot happen with the checks in main(); kept loud
+            log(f"result line reports n_gpus = {got}, asked for {n}")
+            rc = 1
+    if line is not None:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +223,7 @@ def main():
                     "num_keypoint_detection=3) = HRNet every int(FPS/3)-th frame, optical-flow propagation in between (stateful; reported as reference_cadence, never as value)")
     ap.add_argument("--latency-calls", type=int, default=200, help="calls per row of the small-batch latency table (0: skip)")
     ap.add_argument("--latency-only", action="store_true", help="developer: print only the small-batch latency table (all modes: multi-stream / hipGraph on and off)")
+    ap.add_argument("--print-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the command the parent would start (one JSON object) and exit")
     ap.add_argument("--gather", default="rccl", choices=["rccl", "dist"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo + --shared-gpu: dev test of the multi-rank path on one GPU)")
     ap.add_argument("--shared-gpu", action="store_true", help="every rank uses HIP device 0 (developer test only)")
@@ -192,6 +239,14 @@ def main():
     if a.cpu_baseline_only:                                # (the child of the default run: prints its own one-line JSON object for the parent)
         cpu_baseline_child(a)
         return
+    # --gpus N against the launcher's environment, BEFORE anything touches the GPU or loads the HIP library (VERDICT r5 task 3):
+    #   WORLD_SIZE unset, N > 1 : this process is not a rank — it becomes the launcher (self_launch: fresh child processes through torch.distributed.run, never exec)
+    #   WORLD_SIZE set, != N    : a mismatch is an error, never a silent one-GPU measurement labelled n_gpus = 1
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            sys.exit(self_launch(a.gpus, sys.argv[1:], print_only=a.print_launch))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to measure a different GPU count than the one asked for")
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
@@ -199,8 +254,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     multi = world > 1 or a.force_multirank_path
 
     cpu_base = None

@@ -86,6 +86,19 @@ inline bool prec_is_f16_kernels(int precision) { return precision == EAGLE_PREC_
 // plain_epilogue: pre_act none, post_act none/ReLU, at most one residual, fp16 output (what the weight-stationary kernel implements)
 ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_pad, int wo, bool plain_epilogue = false, bool second_residual = false, bool any_residual = true);
 
+// ---- fused Bottleneck (bneck.hip; EAGLE_PREC_F32S): conv1 1x1 Cin->64 + ReLU, conv2 3x3 64->64 + ReLU, conv3 1x1 64->256 + residual + ReLU in one launch ----
+struct BneckLaunch {
+    TView x, res, y;         // res: the 256-channel residual operand (x itself for an identity shortcut)
+    const void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;      // fragment-major weight images (bneck_tile_weights)
+    const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;     // folded-BN biases
+    float ds1 = 1.f, ds2 = 1.f, ds3 = 1.f;
+    unsigned* const* sat_slot = nullptr;
+};
+bool bneck_supported(const TView& x, int cmid, int cout);
+// w: folded fp32 weights [taps][cin][cout] (taps = 1 or 9)
+void bneck_tile_weights(const float* w, int taps, int cin, int cout, std::vector<_Float16>& out, float* descale);
+void bneck_launch(const BneckLaunch& L, hipStream_t s);
+
 // ---- other kernels ----------------------------------------------------------------------------------------
 struct LetterBox { int new_h, new_w, top, left, out_h, out_w; };
 LetterBox letterbox_geometry(int h, int w, int imgsz);

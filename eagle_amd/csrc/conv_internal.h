@@ -31,6 +31,15 @@ struct ConvArgs {
                             // +-4094 adds one to its frame's word), or nullptr: not counted (operator-level calls)
 };
 
+struct BneckArgs {          // bneck.hip; channel strides / offsets in fp16 elements (two per logical channel)
+    const void* x; int xcs, xoff; int N, H, W, nch1;      // nch1 = Cin / 16
+    const void *w1, *w2, *w3; const float *b1, *b2, *b3; float ds1, ds2, ds3;
+    const void* r; int rcs, roff;
+    void* y; int ycs, yoff;
+    int tiles_x, tiles_y;
+    unsigned* sat;
+};
+
 typedef void (*ConvKernel)(ConvArgs);
 struct Inst { int prec, ks, s, kc, nt, variant; ConvKernel fn; };
 const Inst* conv_inst_part(int part, int* n);       // instance tables of conv_inst_0..3.hip (declared per part below)

@@ -365,6 +365,58 @@ struct Builder {
         net->ops.push_back(op);
         return L.y;
     }
+    // folded weights of conv `cname` (+ BatchNorm `bn`) as [tap][cin][cout] and the folded bias: the arithmetic of conv() above, for the fused launches
+    void fold(const std::string& cname, const std::string& bn, std::vector<float>& hwio, std::vector<float>& bias, int& cin, int& cout, int& ks)
+    {
+        const HostTensor& w = W(cname + ".weight");
+        if (w.shape.size() != 4) fail(EAGLE_E_INVALID, "%s.weight: expected 4-d", cname.c_str());
+        cout = (int)w.shape[0]; cin = (int)w.shape[1]; ks = (int)w.shape[2];
+        hwio.assign((size_t)ks * ks * cin * cout, 0.f); bias.assign(cout, 0.f);
+        std::vector<double> scale(cout, 1.0);
+        const HostTensor &g = W(bn + ".weight"), &b = W(bn + ".bias"), &m = W(bn + ".running_mean"), &v = W(bn + ".running_var");
+        for (int o = 0; o < cout; ++o) {
+            scale[o] = (double)g.data[o] / std::sqrt((double)v.data[o] + bn_eps);
+            bias[o] = (float)((double)b.data[o] - (double)m.data[o] * scale[o]);
+        }
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin; ++i)
+                for (int t = 0; t < ks * ks; ++t)
+                    hwio[((size_t)t * cin + i) * cout + o] = (float)((double)w.data[((size_t)o * cin + i) * ks * ks + t] * scale[o]);
+    }
+    // One launch for a whole Bottleneck (bneck.hip): relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + res), kh.py:101-137
+    TView bottleneck(const TView& x, const std::string& q, const TView& res)
+    {
+        BneckLaunch L;
+        std::vector<float> hw, bs; int ci, co, ks;
+        std::vector<_Float16> img;
+        double flop = 0;
+        const char* cn[3] = {"conv1", "conv2", "conv3"}; const char* bnn[3] = {"bn1", "bn2", "bn3"};
+        const int want_ks[3] = {1, 3, 1}, want_ci[3] = {x.c, 64, 64}, want_co[3] = {64, 64, 256};
+        for (int k = 0; k < 3; ++k) {
+            fold(q + cn[k], q + bnn[k], hw, bs, ci, co, ks);
+            if (ks != want_ks[k] || ci != want_ci[k] || co != want_co[k]) fail(EAGLE_E_INVALID, "%s%s: not the Bottleneck shape of the fused kernel", q.c_str(), cn[k]);
+            float ds = 1.f;
+            bneck_tile_weights(hw.data(), ks * ks, ci, co, img, &ds);
+            const void* dw = net->upload(img.data(), img.size() * 2);
+            const float* db = (const float*)net->upload(bs.data(), bs.size() * 4);
+            if (k == 0) { L.w1 = dw; L.b1 = db; L.ds1 = ds; } else if (k == 1) { L.w2 = dw; L.b2 = db; L.ds2 = ds; } else { L.w3 = dw; L.b3 = db; L.ds3 = ds; }
+            flop += 2.0 * N * x.h * x.w * (double)co * ci * ks * ks;
+        }
+        L.x = x; L.res = res; L.y = act(x.h, x.w, 256);
+        L.sat_slot = &H->cur_sat;
+        for (const TView* t : {&L.x, &L.y, &L.res})
+            if ((size_t)t->n * t->h * t->w * t->cs * t->esize() >= ((size_t)1 << 31))
+                fail(EAGLE_E_INVALID, "%s: a %d x %d x %d x %d-channel tensor of this block reaches 2 GiB at a device batch of %d frames (32-bit tensor offsets); use a smaller EagleConfig.batch",
+                     q.c_str(), t->n, t->h, t->w, t->cs, N);
+        char label[64];
+        snprintf(label, sizeof(label), "bneck %d->64->256 @%dx%d%s", x.c, x.h, x.w, label_suffix);
+        net->names.emplace_back(new std::string(label));
+        Op op; op.kind = Op::CONV; op.flop = flop; op.tag = net->names.back()->c_str(); op.stream = cur_stream;
+        op.bytes = (double)N * x.h * x.w * 4.0 * (x.c + 256 + (res.p == x.p ? 0 : 256)) + 4.0 * (x.c * 64 + 9 * 64 * 64 + 64 * 256);      // x once, y once (+ a separate residual tensor), weights once
+        op.run = [L](hipStream_t s) { bneck_launch(L, s); };
+        net->ops.push_back(op);
+        return L.y;
+    }
     static double vbytes(const TView& v) { return (double)v.n * v.h * v.w * v.c * (v.f32 ? 4 : 2); }
     void other(std::function<void(hipStream_t)> fn, const char* tag, double bytes = 0)
     {
@@ -459,6 +511,15 @@ static TView build_hrnet(Builder& B, const TView& x_in)
         const std::string q = P + "layer1." + std::to_string(b) + ".";
         TView res = x;
         if (b == 0) res = B.conv(x, q + "downsample.0", q + "downsample.1", 1, 0, nullptr, nullptr, 0);
+        // round 6: the whole Bottleneck as one launch in the split family (EAGLE_BNECK_FUSED=0: the three launches of rounds 1-5)
+        const char* fe = getenv("EAGLE_BNECK_FUSED");
+        if (B.prec == EAGLE_PREC_F32S && !(fe && atoi(fe) == 0) && bneck_supported(x, 64, 256)) {
+            TView y = B.bottleneck(x, q, res);
+            if (b == 0) B.release(res);
+            B.release(x);
+            x = y;
+            continue;
+        }
         TView o1 = B.conv(x, q + "conv1", q + "bn1", 1, 0, nullptr, nullptr, R);
         TView o2 = B.conv(o1, q + "conv2", q + "bn2", 1, 0, nullptr, nullptr, R);
         TView y = B.conv(o2, q + "conv3", q + "bn3", 1, 0, &res, nullptr, R);
@@ -1992,6 +2053,41 @@ int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int
     conv_launch(precision, L, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     from_dev(L.y, cout, y);
+    API_END(hh)
+}
+
+int eagle_op_bottleneck(int device, const float* x, int n, int h, int w, int cin, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* w3, const float* b3, const float* res, float* y, int reps, float* ms)
+{
+    EagleHandle* hh = nullptr;
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !y || n < 1 || h < 1 || w < 1 || cin % 16 || cin < 16) fail(EAGLE_E_INVALID, "eagle_op_bottleneck: bad argument (Cin must be a multiple of 16)");
+    if (!res && cin != 256) fail(EAGLE_E_INVALID, "eagle_op_bottleneck: an identity shortcut needs Cin = 256");
+    Net net;
+    BneckLaunch L;
+    to_dev(net, EAGLE_PREC_F32S, x, n, h, w, cin, cin, L.x);
+    if (res) to_dev(net, EAGLE_PREC_F32S, res, n, h, w, 256, 256, L.res); else L.res = L.x;
+    L.y = L.res; L.y.p = net.get((size_t)n * h * w * 256 * 4);
+    std::vector<_Float16> img;
+    bneck_tile_weights(w1, 1, cin, 64, img, &L.ds1); L.w1 = net.upload(img.data(), img.size() * 2);
+    bneck_tile_weights(w2, 9, 64, 64, img, &L.ds2); L.w2 = net.upload(img.data(), img.size() * 2);
+    bneck_tile_weights(w3, 1, 64, 256, img, &L.ds3); L.w3 = net.upload(img.data(), img.size() * 2);
+    L.b1 = (const float*)net.upload(b1, 64 * 4); L.b2 = (const float*)net.upload(b2, 64 * 4); L.b3 = (const float*)net.upload(b3, 256 * 4);
+    bneck_launch(L, nullptr);
+    HIP_CHECK(hipDeviceSynchronize());
+    if (reps > 0 && ms) {                                   // developer timing: the launch alone, HIP events on the launch stream
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) bneck_launch(L, nullptr);
+        HIP_CHECK(hipEventRecord(e1, nullptr));
+        HIP_CHECK(hipEventSynchronize(e1));
+        HIP_CHECK(hipEventElapsedTime(ms, e0, e1));
+        *ms /= (float)reps;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    from_dev(L.y, 256, y);
     API_END(hh)
 }
 

@@ -127,6 +127,7 @@ def load():
     L.eagle_get_timings.argtypes = [vp, C.POINTER(EagleTimings)]
     L.eagle_get_kernel_times.argtypes = [vp, C.POINTER(EagleKernelTime), i32, C.POINTER(i32)]
     L.eagle_op_conv2d.argtypes = [i32, i32, fp, i32, i32, i32, i32, fp, fp, i32, i32, i32, i32, fp, fp, i32, fp]
+    L.eagle_op_bottleneck.argtypes = [i32, fp, i32, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32, fp]
     L.eagle_op_fuse_sum.argtypes = [i32, i32, fp, i32, i32, i32, i32, i32, C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, fp]
     L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
     L.eagle_op_find_homography.argtypes = [i32, fp, fp, i32, C.c_double, i32, i32, dp, u8p, C.POINTER(i32)]
@@ -483,6 +484,22 @@ def op_conv2d(x, w_hwio, bias, stride=1, pre=0, r1=None, r2=None, post=0, precis
     if rc:
         raise EagleError(f"eagle_op_conv2d failed ({rc}): {L.eagle_last_error(None).decode()}")
     return y
+
+
+def op_bottleneck(x, w1, b1, w2, b2, w3, b3, res=None, reps=0, device=0):
+    """One fused Bottleneck launch of the split family (include/eagle.h eagle_op_bottleneck; csrc/bneck.hip).  Returns y, or (y, ms per launch) when reps > 0."""
+    L = load()
+    x = np.ascontiguousarray(x, np.float32)
+    n, h, w, cin = x.shape
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (w1, b1, w2, b2, w3, b3)]
+    assert arrs[0].shape == (1, 1, cin, 64) and arrs[2].shape == (3, 3, 64, 64) and arrs[4].shape == (1, 1, 64, 256), "HWIO weights of a 64-wide Bottleneck"
+    res = None if res is None else np.ascontiguousarray(res, np.float32)
+    y = np.empty((n, h, w, 256), np.float32)
+    ms = C.c_float(0)
+    rc = L.eagle_op_bottleneck(device, _fp(x), n, h, w, cin, *[_fp(a) for a in arrs], _fp(res), _fp(y), int(reps), C.byref(ms))
+    if rc:
+        raise EagleError(f"eagle_op_bottleneck failed ({rc}): {L.eagle_last_error(None).decode()}")
+    return (y, ms.value) if reps > 0 else y
 
 
 def op_fuse_sum(base, ups, relu=True, precision=PREC_F32, device=0):

@@ -272,6 +272,11 @@ int eagle_get_kernel_times(EagleHandle* h, EagleKernelTime* out, int cap, int* n
 int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int w, int cin, const float* w_hwio,
                     const float* bias, int cout, int ks, int stride, int pre_act, const float* r1, const float* r2,
                     int post_act, float* y);
+/* One fused Bottleneck of HRNet's layer 1 in the split family (bneck.hip; kh.py:101-137): y = relu(conv3(relu(conv2(relu(conv1(x))))) + res), conv1 1x1 Cin->64,
+ * conv2 3x3 64->64, conv3 1x1 64->256, BatchNorm already folded into (w, b); weights HWIO ([1][1][Cin][64], [3][3][64][64], [1][1][64][256]); res = NULL: the
+ * identity shortcut (Cin = 256).  reps > 0: *ms = average duration of `reps` further launches (HIP events). */
+int eagle_op_bottleneck(int device, const float* x, int n, int h, int w, int cin, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* w3, const float* b3, const float* res, float* y, int reps, float* ms);
 int eagle_op_fuse_sum(int device, int precision, const float* base, int n, int H, int W, int c, int n_up,
                       const float* const* ups, const int* up_h, const int* up_w, int relu, float* y);
 int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz,

@@ -1,0 +1,81 @@
+"""-m gpu: the fused Bottleneck launch of HRNet's layer 1 (csrc/bneck.hip, round 6; eagle/models/keypoint_hrnet.py:101-137) through the C ABI's
+operator entry, against (a) the fp32 oracle's three convolutions and (b) the three unfused split-family launches it replaces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F32S_TOL = 4e-6          # one split-family convolution against the fp32 oracle (tests/test_gpu_ops.py)
+BNECK_TOL = 3 * F32S_TOL  # three chained convolutions, the two intermediates rounded to the split format (22+ bits) where the oracle keeps fp32
+
+
+def _rand(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def _weights(cin, seed):
+    w1 = _rand((1, 1, cin, 64), seed, (2.0 / cin) ** 0.5); b1 = _rand((64,), seed + 1, 0.1)
+    w2 = _rand((3, 3, 64, 64), seed + 2, (2.0 / 576) ** 0.5); b2 = _rand((64,), seed + 3, 0.1)
+    w3 = _rand((1, 1, 64, 256), seed + 4, (2.0 / 64) ** 0.5); b3 = _rand((256,), seed + 5, 0.1)
+    return w1, b1, w2, b2, w3, b3
+
+
+def _oracle(x, ws, res):
+    from oracle import prims as P
+    w1, b1, w2, b2, w3, b3 = ws
+    t1 = P.conv2d(x, w1, b1, stride=1, pre=0, r1=None, r2=None, post=1)
+    t2 = P.conv2d(t1, w2, b2, stride=1, pre=0, r1=None, r2=None, post=1)
+    return P.conv2d(t2, w3, b3, stride=1, pre=0, r1=x if res is None else res, r2=None, post=1)
+
+
+SHAPES = [(1, 8, 32), (2, 19, 45), (3, 1, 1), (1, 7, 65), (5, 17, 30), (1, 9, 33), (2, 16, 64)]
+
+
+@pytest.mark.parametrize("wgs", ["256", "8"])
+@pytest.mark.parametrize("cin", [256, 64, 16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fused_bottleneck_against_the_oracle(shape, cin, wgs, monkeypatch):
+    """Ragged maps, partial tiles in both directions, a 1 x 1 map, several tiles per workgroup (EAGLE_BNECK_WGS=8: the x ring runs on across items and the
+    next tile's first chunks are requested under phases 2 / 3), the identity shortcut (Cin = 256) and a separate residual tensor (block 0: Cin = 64)."""
+    from eagle_amd import lib
+    monkeypatch.setenv("EAGLE_BNECK_WGS", wgs)
+    n, h, w = shape
+    x = _rand((n, h, w, cin), 71)
+    ws = _weights(cin, 72)
+    res = None if cin == 256 else _rand((n, h, w, 256), 79)
+    ref = _oracle(x, ws, res)
+    got = lib.op_bottleneck(x, *ws, res=res)
+    err = np.abs(ref - got).max() / max(np.abs(ref).max(), 1e-6)
+    assert err < BNECK_TOL, f"fused bottleneck error {err}"
+
+
+@pytest.mark.parametrize("cin", [256, 64])
+def test_fused_bottleneck_full_map_against_the_unfused_launches(cin, monkeypatch):
+    """One 135 x 240 frame (HRNet's layer-1 map: 17 x 8 tiles, the last tile row one pixel row short, the last column half empty) with 17 tiles per workgroup,
+    against the three launches the kernel replaces (same family, same rounding of t1 / t2 to the split format) and against the oracle."""
+    from eagle_amd import lib
+    monkeypatch.setenv("EAGLE_BNECK_WGS", "8")
+    x = np.maximum(_rand((1, 135, 240, cin), 81), 0)          # post-ReLU activations, as in the network
+    ws = _weights(cin, 82)
+    w1, b1, w2, b2, w3, b3 = ws
+    res = None if cin == 256 else _rand((1, 135, 240, 256), 89)
+    got = lib.op_bottleneck(x, *ws, res=res)
+    t1 = lib.op_conv2d(x, w1, b1, 1, 0, None, None, 1, lib.PREC_F32S)
+    t2 = lib.op_conv2d(t1, w2, b2, 1, 0, None, None, 1, lib.PREC_F32S)
+    unf = lib.op_conv2d(t2, w3, b3, 1, 0, x if res is None else res, None, 1, lib.PREC_F32S)
+    scale = max(np.abs(unf).max(), 1e-6)
+    assert np.abs(unf - got).max() / scale < BNECK_TOL
+    ref = _oracle(x, ws, res)
+    assert np.abs(ref - got).max() / scale < BNECK_TOL
+
+
+def test_fused_bottleneck_zero_padding_of_the_intermediate():
+    """conv2 pads t1 with ZEROS, not with relu(b1): a kernel that computed conv1 on the out-of-image halo and kept the result would differ on every border pixel.
+    Large positive conv1 biases make that difference huge."""
+    from eagle_amd import lib
+    x = _rand((1, 11, 37, 256), 91)
+    w1, b1, w2, b2, w3, b3 = _weights(256, 92)
+    b1 = np.abs(b1) + 3.0
+    ref = _oracle(x, (w1, b1, w2, b2, w3, b3), None)
+    got = lib.op_bottleneck(x, w1, b1, w2, b2, w3, b3)
+    assert np.abs(ref - got).max() / np.abs(ref).max() < BNECK_TOL

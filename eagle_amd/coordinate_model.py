@@ -21,7 +21,9 @@ class CoordinateModel:
     def __init__(self, keypoint_conf: float = 0.3, detector_conf: float = 0.35, *, frame_hw=(720, 1280),
                  detector="n", det_imgsz=640, batch=8, precision="f32s", device=0, hrnet_state_dict=None,
                  detector_state_dict=None, seed=0, use_graph=None, multi_stream=None, tracker=False, camera_motion=False, detector_precision=None,
-                 reid=False, reid_state_dict=None, allow_saturation=False):
+                 reid=False, reid_state_dict=None, allow_saturation=False, letterbox="rect"):
+        # letterbox: "rect" = ultralytics LetterBox(auto=True), what the reference's .pt detectors run with (cm.py:56-57); "square" = auto=False, the static
+        # det_imgsz x det_imgsz input of its exported ONNX detector (the CPU default, cm.py:54-55)
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self.tracker = tracker
         if camera_motion not in (False, True, None, "sparse", "ecc"):
@@ -34,11 +36,11 @@ class CoordinateModel:
         # classes, NMS order and hence every detection-index id equal the fp32 reference arithmetic bit for bit), otherwise in `precision`
         dp = {} if detector_precision is None else {"det_precision": lib.PRECISIONS[detector_precision] + 1}
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
-                                 det_imgsz=det_imgsz, batch=batch,
+                                 det_imgsz=det_imgsz, batch=batch, letterbox=letterbox,
                                  precision=lib.PRECISIONS[precision],
                                  keypoint_conf=keypoint_conf, detector_conf=detector_conf,
                                  detector_floor=min(detector_conf, 0.15),
-                                 use_graph=lib.AUTO if use_graph is None else int(bool(use_graph)),         # None: the library's small-batch rule (include/eagle.h EAGLE_SMALL_BATCH)
+                                 use_graph=self._graph_mode(use_graph),         # None: the library's small-batch rule (include/eagle.h EAGLE_SMALL_BATCH); 0 / 1 / 2 pass through
                                  multi_stream=lib.AUTO if multi_stream is None else int(bool(multi_stream)),
                                  allow_saturation=int(allow_saturation), **dp)
         # the reference reads eagle/models/weights/*.pt|.pth (cm.py:55-59); none exist here -> seeded synthetic
@@ -49,6 +51,19 @@ class CoordinateModel:
             from . import osnet
             sds.append(reid_state_dict if reid_state_dict is not None else osnet.make_osnet_state_dict(seed))
         weights.load_into(self.handle, sds)
+
+    @staticmethod
+    def _graph_mode(use_graph):
+        """EagleConfig::use_graph: None -> EAGLE_AUTO; False / True -> 0 / 1; the integers 0, 1, 2 as they are (2 = replay only inside calls of at least three
+        steps).  Round 5 mapped everything through bool(): mode 2 silently became per-step replay."""
+        if use_graph is None:
+            return lib.AUTO
+        if isinstance(use_graph, (bool, np.bool_)):
+            return int(use_graph)
+        m = int(use_graph)
+        if m not in (0, 1, 2):
+            raise ValueError(f"use_graph must be None, a bool, or 0 / 1 / 2 (got {use_graph!r})")
+        return m
 
     # ---- raw records ---------------------------------------------------------------------------------
     def process_records(self, frames):

@@ -7,20 +7,23 @@
 // one read and one write of the 256-channel tensor are 3.3 GB.  These were the only HBM-bound convolutions left in the network
 // (VERDICT r5 weak #4): the kernel below is memory-bound by design (3552 MFMAs of 32 cycles per 852 KB of tile traffic).
 //
-// Workgroup = 8 waves (one per CU, 160 KB of LDS), tile = 8 rows x 32 columns of output pixels, persistent over an XCD-contiguous range of
+// Workgroup = 8 waves (one per CU, 155 KB of LDS), tile = 8 rows x 32 columns of output pixels, persistent over an XCD-contiguous range of
 // tiles in column-major order (the tile below is the next item of the same workgroup: its two shared halo rows are L2 hits).
 //   phase 1  conv1 over the 10 x 34 halo (340 pixels = 11 blocks of 32 in LINEAR halo order, no row quantisation): x streams through a
-//            two-deep LDS-DMA ring in 16-channel chunks (80-byte records [hi g0][hi g1][lo g0][lo g1] + pad, conflict-free ds_read_b128),
-//            weights straight from L2 into registers (fragment-major image), v_mfma_f32_32x32x16_f16, three products per chunk
-//            (Whi Xhi + Whi Xlo + Wlo Xhi).  The ring runs on across items: the next tile's first two chunks are requested during the
-//            current tile's phases 2 / 3.
+//            two-deep LDS-DMA ring in 16-channel chunks (80-byte records [hi g0][hi g1][lo g0][lo g1] + pad, conflict-free ds_read_b128).
+//            The ring is WAVE-PRIVATE: a wave owns one or two of the 11 pixel blocks (all 64 output channels of them), requests, waits for
+//            (vmcnt) and reads only its own records — NO barrier in the whole phase, every wave streams at its own pace, and the first two
+//            chunks of the next tile are requested while the wave still has phases 2 / 3 of this one in front of it.  Weights straight from L2
+//            into registers (fragment-major image), v_mfma_f32_32x32x16_f16, three products per chunk (Whi Xhi + Whi Xlo + Wlo Xhi).
 //   epi 1    t1 = relu(acc * descale + b1), ZERO outside the image (conv2's padding), split -> LDS records of 272 bytes (4 chunks x 64 + 16:
 //            pixel stride = 4 banks mod 64, conflict-free for every tap's fragment read with one address register and immediates)
-//   phase 2  conv2 3x3 from t1 in LDS, weights through a register ring (72 fragment pairs per wave)
+//   phase 2  conv2 3x3 from t1 in LDS (wave: 32 channels x 2 rows), weights through a register ring, B fragments double-buffered
 //   epi 2    t2 = relu(...) -> LDS (over t1, after a barrier)
-//   phase 3  conv3 in two passes of 128 output channels, B fragments from t2; epilogue through a wave-private 4-KB strip: the residual (the
-//            block's own input x for blocks 1..3 — read ~50 us after phase 1 loaded it — or the downsample branch's output for block 0) in as
-//            coalesced 16-byte pieces, + bias, ReLU, split, out as non-temporal 16-byte stores.
+//   phase 3  conv3 in four passes of 64 output channels (wave: 32 of them x 2 rows), B fragments from t2; epilogue through a wave-private 4-KB
+//            strip: the residual (the block's own input x for blocks 1..3 — read ~50 us after phase 1 loaded it — or the downsample branch's
+//            output for block 0) in as coalesced 16-byte pieces, + bias, ReLU, split, out as non-temporal 16-byte stores.  The residual pieces
+//            of a pass are requested one pass ahead (those of pass 0 before phase 2), the weight fragments right after the previous pass' MFMAs.
+// Four workgroup barriers per tile (round 6's first form had twenty: one per chunk of phase 1).
 // Numerics: the same three-product split scheme, power-of-two operand scaling and fp32 accumulation as conv_ad_split32.inc; t1 / t2 are
 // rounded to the split format exactly as the unfused launches round them when they store, so the result differs from the unfused path only
 // by the summation order inside an accumulator (fp32-order noise; tests/test_gpu_bneck.py holds it at F32S_TOL against the fp32 oracle).
@@ -38,6 +41,19 @@ namespace eagle {
 #include "conv_kernels.inc"
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// -DEAGLE_BNECK_TIMING (developer builds): wave 0 accumulates the s_memrealtime span of every phase of its items into BneckArgs::dbg[blockIdx * 8 + phase]
+#ifndef EAGLE_BNECK_FORM_DEFAULT
+#define EAGLE_BNECK_FORM_DEFAULT 0
+#endif
+#ifndef EAGLE_BNECK_TIMING
+#define EAGLE_BNECK_TIMING 0
+#endif
+#if EAGLE_BNECK_TIMING
+#define BN_TICK(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define BN_TICK(k) do { } while (0)
+#endif
 
 // -DEAGLE_ABL_BNECK=n (developer ablation builds only; results are garbage, only the time is of interest): 1 no x requests after the workgroup's first
 // two, 2 no MFMAs, 3 no residual loads / output stores, 4 phase 2 skipped, 5 phase 3's MFMAs skipped
@@ -58,28 +74,37 @@ __device__ __forceinline__ void bn_split4(float v0, float v1, float v2, float v3
     lo = half4{(_Float16)(s0 - (float)hi[0]), (_Float16)(s1 - (float)hi[1]), (_Float16)(s2 - (float)hi[2]), (_Float16)(s3 - (float)hi[3])};
 }
 
-constexpr int BNK_TH = 8, BNK_TW = 32, BNK_NW = 8;
-constexpr int BNK_HW = BNK_TW + 2, BNK_HPIX = (BNK_TH + 2) * BNK_HW;      // 34, 340
-constexpr int BNK_PS = 80, BNK_XSL = 28, BNK_XB = BNK_XSL * 1024;        // x ring: 80-byte records, 28 slabs of 1 KiB per slot (340 x 80 = 27200 B; block 10 reads up to pixel 351 = 28160 B)
-constexpr int BNK_TPS = 272;                                              // t1 / t2 record: 64 channels x 4 bytes + 16
-constexpr int BNK_T2B = BNK_TH * BNK_TW * BNK_TPS, BNK_STRIP = 4096;      // 69632
-constexpr int BNK_REG = BNK_T2B + BNK_NW * BNK_STRIP;                     // 102400: t1 (92480) | t2 + strips
-constexpr int BNK_LDS = BNK_REG + 2 * BNK_XB + 1024;                      // 160768 (+ 1 KiB scratch slab for the dummy requests)
-static_assert(BNK_REG >= BNK_HPIX * BNK_TPS, "t1 fits the region");
-static_assert(BNK_LDS <= 160 * 1024, "LDS");
+// Tile forms.  <TH = 8, NSLOT = 2>: 8 waves, ONE workgroup per CU (155 KB of LDS), two-deep x ring.  <TH = 4, NSLOT = 1>: 4 waves, tile 4 x 32, 72 KB of LDS — TWO workgroups
+// per CU, whose phases interleave on the CU (one streams x or stores while the other issues MFMAs); the x ring has ONE slot per wave (the next chunk is requested when the
+// wave has read the current one; the CU's other workgroup covers the latency), conv1 is recomputed on 1.59x instead of 1.33x the pixels.
+constexpr int BNK_TW = 32, BNK_HW = BNK_TW + 2, BNK_PS = 80, BNK_PBB = 32 * BNK_PS, BNK_TPS = 272, BNK_STRIP = 4096;
+template <int TH, int NSLOT>
+struct BneckGeom {
+    static constexpr int NW = TH;                                        // waves per workgroup: wave (q = w >> 1, mb = w & 1) owns rows q and q + TH / 2 in phases 2 / 3
+    static constexpr int HPIX = (TH + 2) * BNK_HW;                       // 340 / 204 halo pixels
+    static constexpr int NPB = (HPIX + 31) / 32, N2 = NPB - NW;          // 11 / 7 pixel blocks of phase 1; waves 0 .. N2 - 1 own two of them, the others one
+    static constexpr int XB = NPB * BNK_PBB;                             // bytes of one ring slot (all waves' private regions)
+    static constexpr int T2B = TH * BNK_TW * BNK_TPS;
+    static constexpr int REG = (HPIX * BNK_TPS > T2B + NW * BNK_STRIP) ? HPIX * BNK_TPS : T2B + NW * BNK_STRIP;      // t1 | t2 + strips
+    static constexpr int LDS = REG + NSLOT * XB;
+    static_assert(N2 >= 0 && N2 <= NW && LDS <= 160 * 1024, "geometry");
+};
 
-__global__ __launch_bounds__(512, 2) void bneck_split_kernel(BneckArgs a)
+template <int TH, int NSLOT>
+__global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
 {
+    using G = BneckGeom<TH, NSLOT>;
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int TH = BNK_TH, TW = BNK_TW, HW_ = BNK_HW, HPIX = BNK_HPIX, NW = BNK_NW, PS = BNK_PS, XSL = BNK_XSL, XB = BNK_XB, TPS = BNK_TPS;
+    constexpr int TW = BNK_TW, HW_ = BNK_HW, HPIX = G::HPIX, PS = BNK_PS, PBB = BNK_PBB, XB = G::XB, TPS = BNK_TPS, RH = TH / 2, N2 = G::N2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const T = smem;                                  // t1, then t2 (+ strips behind t2)
-    char* const Xr = smem + BNK_REG;                       // 2 x XB
-    char* const scratch = Xr + 2 * XB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = lane >> 5, lx = lane & 31, mbw = wave & 1, q = wave >> 1;
-    char* const strip = smem + BNK_T2B + wave * BNK_STRIP;
+    char* const strip = smem + G::T2B + wave * BNK_STRIP;
+    // phase 1: this wave's pixel blocks of the halo (linear halo order) and its private ring region
+    const int npb = wave < N2 ? 2 : 1, pb0 = wave < N2 ? 2 * wave : wave + N2;
+    char* const Xw = smem + G::REG + pb0 * PBB;      // + slot * XB
     const int nitems = a.tiles_x * a.tiles_y * a.N, nwg = gridDim.x;
     int item0, item_end;
     {
@@ -105,103 +130,165 @@ __global__ __launch_bounds__(512, 2) void bneck_split_kernel(BneckArgs a)
         ty = t % a.tiles_y; t /= a.tiles_y;
         tx = t % a.tiles_x; n = t / a.tiles_x;
     };
-    // ---- x ring: request k of this wave fills slab k * 8 + wave (16-byte slot e = slab * 64 + lane: halo pixel e / 5, record slot e % 5; slot 4 = padding) ----
-    int hpk[4];
+    // ---- x ring: request k of this wave fills the 1-KiB slab k of its region (16-byte slot e = k * 64 + lane: local pixel e / 5, record slot e % 5; slot 4 = padding) ----
+    int hpk[5];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int slab = k * NW + wave, e = slab * 64 + lane;
-        const int pix = e / 5, slot = e - pix * 5;
+    for (int k = 0; k < 5; ++k) {
+        const int e = k * 64 + lane;
+        const int lp = e / 5, slot = e - lp * 5, pix = pb0 * 32 + lp;
         const int hy = pix / HW_, hx = pix - hy * HW_;
-        // record slot (hi g0, hi g1, lo g0, lo g1) <- the tensor's 16-byte unit (hi g0, lo g0, hi g1, lo g1)
-        hpk[k] = (slab < XSL && pix < HPIX && slot < 4) ? (hy | (hx << 8) | (((slot & 1) * 2 + (slot >> 1)) << 16)) : -1;
+        // record slot (hi g0, hi g1, lo g0, lo g1) <- the tensor's 16-byte unit (hi g0, lo g0, hi g1, lo g1); -2: the lane lies beyond the wave's region (no request at all)
+        hpk[k] = lp >= 32 * npb ? -2 : (pix < HPIX && slot < 4) ? (hy | (hx << 8) | (((slot & 1) * 2 + (slot >> 1)) << 16)) : -1;
     }
-    int issued = 0, g = 0;                                 // chunks requested / chunk being consumed (global over the workgroup's items)
+    int issued = 0, g = 0;                                 // chunks requested / chunk being consumed (global over the workgroup's items); per wave
     int r_item = item0, r_ch = 0, r_iy0 = 0, r_ix0 = 0, r_gb = 0;
     auto req_origin = [&](int item) {
         int n, ty, tx; decode(item, n, ty, tx);
         r_iy0 = ty * TH - 1; r_ix0 = tx * TW - 1;
         r_gb = (((n * a.H + r_iy0) * a.W + r_ix0) * a.xcs + a.xoff) * 2;
     };
-    auto issue_x = [&]() {                                 // requests chunk number `issued`
-        char* const dst = Xr + (issued & 1) * XB;
+    auto issue_x = [&]() {                                 // requests chunk number `issued` (this wave's pixels) into slot issued & 1
+        char* const dst = Xw + (issued % NSLOT) * XB;
         const unsigned so = (unsigned)(r_ch * 64);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int slab = k * NW + wave;
+        for (int k = 0; k < 5; ++k) {
+            if (k >= 3 && npb == 1) continue;              // (wave-uniform)
             const int hy = hpk[k] & 0xFF, hx = (hpk[k] >> 8) & 0xFF, unit = (hpk[k] >> 16) & 7;
             const int iy = r_iy0 + hy, ix = r_ix0 + hx;
             const unsigned off = !(hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? OOB
                                  : (unsigned)(r_gb + ((hy * a.W + hx) * a.xcs + unit * 8) * 2);
-            char* const d = slab < XSL ? dst + slab * 1024 : scratch;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)d, 16, (EAGLE_ABL_BNECK == 1 && issued >= 2) ? OOB : off, so, 0, 0);
+            if (hpk[k] != -2)                               // (lanes beyond the region are masked off: LDS-DMA writes nothing for inactive lanes)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, (EAGLE_ABL_BNECK == 1 && issued >= NSLOT) ? OOB : off, so, 0, 0);
         }
         ++issued;
         if (++r_ch == nch1) { r_ch = 0; ++r_item; if (r_item < item_end) req_origin(r_item); }
     };
     req_origin(item0);
     issue_x();
-    if (GC > 1) issue_x();
+    if (NSLOT > 1 && GC > 1) issue_x();
 
-    const unsigned w1lane = (unsigned)(mbw * 1024 + lane * 16);
-    const int pb2 = q == 3 ? 10 : q + 8;                   // third pixel block of the wave in phase 1 (q = 3: a duplicate of block 10, not stored)
+    const unsigned wlane = (unsigned)(lane * 16), w1lane = (unsigned)(mbw * 1024 + lane * 16);
+#if EAGLE_BNECK_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int item = item0; item < item_end; ++item) {
         int n, ty, tx; decode(item, n, ty, tx);
         const int oy0 = ty * TH, ox0 = tx * TW;
         float vmax = 0.0f;
-        // =============================== phase 1: conv1 over the halo ===============================
-        f32x16 acc1[3];
+        // =============================== phase 1: conv1 over the halo (no barrier: every wave streams its own pixel blocks) ===============================
+        f32x16 acc1[2][2];                                  // [local pixel block][channel block]
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[k][r] = 0.f;
-        // weight image 1: [chunk][hi | lo][2 blocks][lane][8]
-        u32x4 Ah = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1lane, 0, 0), Al = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1lane + 2048, 0, 0);
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[j][m][r] = 0.f;
+        // weight image 1: [chunk][hi | lo][2 blocks][lane][8]: 4 KiB per chunk
+        u32x4 A1[2][2];                                     // [hi | lo][channel block]
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) A1[pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, wlane + (pt * 2 + m) * 1024, 0, 0);
         for (int ch = 0; ch < nch1; ++ch, ++g) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): chunk g (and this chunk's weight fragments) have landed
-            __builtin_amdgcn_s_barrier();                           // ... for every wave, and every wave is done with the other slot
-            if (issued == g + 1 && issued < GC) issue_x();
+            // chunk g has landed: everything older than the requests of chunk g + 1 (3 or 5 per wave) is complete.  The first chunk of an item waits for
+            // everything (output stores of the previous item may still be in flight: stores and loads share the counter)
+            if (NSLOT == 1 || ch == 0 || issued != g + 2) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F75);
+            else __builtin_amdgcn_s_waitcnt(0x0F73);
             const unsigned son = (unsigned)((ch + 1 < nch1 ? ch + 1 : ch) * 4096);
-            const u32x4 Ahn = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1lane, son, 0), Aln = __builtin_amdgcn_raw_buffer_load_b128(w1rs, w1lane + 2048, son, 0);
-            const char* hb = Xr + (g & 1) * XB + lx * PS + kh * 16;
+            u32x4 A1n[2][2];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int pb = k == 2 ? pb2 : q + 4 * k;
-                const half8 Bh = *(const half8*)(hb + pb * 32 * PS), Bl = *(const half8*)(hb + pb * 32 * PS + 32);
-                acc1[k] = BN_MFMA((half8)Ah, Bh, acc1[k]);
-                acc1[k] = BN_MFMA((half8)Ah, Bl, acc1[k]);
-                acc1[k] = BN_MFMA((half8)Al, Bh, acc1[k]);
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) A1n[pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, wlane + (pt * 2 + m) * 1024, son, 0);
+            const char* hb = Xw + (g % NSLOT) * XB + lx * PS + kh * 16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 0 || npb == 2) {
+                const half8 Bh = *(const half8*)(hb + j * PBB), Bl = *(const half8*)(hb + j * PBB + 32);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    acc1[j][m] = BN_MFMA((half8)A1[0][m], Bh, acc1[j][m]);
+                    acc1[j][m] = BN_MFMA((half8)A1[0][m], Bl, acc1[j][m]);
+                    acc1[j][m] = BN_MFMA((half8)A1[1][m], Bh, acc1[j][m]);
+                }
+                }
             }
-            Ah = Ahn; Al = Aln;
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's fragment reads of the slot are complete ...
+            if (issued == g + NSLOT && issued < GC) issue_x();   // ... so chunk g + NSLOT may land in it
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) A1[pt][m] = A1n[pt][m];
         }
-        __builtin_amdgcn_s_barrier();                               // every wave is done with the slot of the item's last chunk
-        if (issued == g + 1 && issued < GC) issue_x();              // the next item's second chunk travels under phases 2 / 3
+        BN_TICK(0);                                                  // phase 1
+        // residual pieces of phase 3's first pass: requested now, they travel under phase 2
+        int pstrip[4], ppx[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = i * 64 + lane, px = e >> 3, u = e & 7;
+            pstrip[i] = px * 128 + ((u ^ (px & 7)) * 16);
+            ppx[i] = px | (u << 8);
+        }
+        // piece e = i * 64 + lane of a block (one row of 32 pixels x 32 channels): pixel e / 8, 16-byte unit e % 8 (4 channel groups x (hi, lo), tensor order)
+        auto piece_off = [&](int ri, int i, int cs, int off) -> unsigned {      // cs / off in fp16 elements; the pass' channel block rides in the scalar offset of the access
+            const int oy = oy0 + q + RH * ri, ox = ox0 + (ppx[i] & 0xFF), u = ppx[i] >> 8;
+            return (oy < a.H && ox < a.W) ? (unsigned)((((n * a.H + oy) * a.W + ox) * cs + off + u * 8) * 2) : OOB;
+        };
+        unsigned poff_r[2][4], poff_y[2][4];
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { poff_r[ri][i] = piece_off(ri, i, a.rcs, a.roff); poff_y[ri][i] = piece_off(ri, i, a.ycs, a.yoff); }
+        // phase 3 works in four passes (pass p: output channels 64 p + 32 mbw .. + 31 of this wave's two rows); the weight fragments and the residual pieces of a pass
+        // are requested one pass ahead into the other half of a double buffer — those of pass 0 here, so that they travel under phase 2.
+        // weight image 3: [chunk][hi | lo][8 blocks][lane][8]
+        u32x4 A3[4][2], rres[2][2][4];
+        auto p3_weights = [&](int pass) {                   // single buffer: requested right after the previous pass' MFMAs, they land under its epilogue
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+                    A3[c][pt] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (unsigned)(((c * 2 + pt) * 8 + pass * 2 + mbw) * 1024 + lane * 16), 0, 0);
+        };
+        auto p3_residual = [&](int buf, int pass) {
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rres[buf][ri][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_r[ri][i], (pass * 2 + mbw) * 128, 0);
+        };
+        p3_residual(0, 0);                                           // (they travel under phase 2)
+        __syncthreads();                                             // every wave has left phase 3 of the previous item: the t1 region is free
+        BN_TICK(1);                                                  // wait for the slowest wave
         // ---- epilogue 1: t1 = relu(acc * ds1 + b1), zero outside the image -> LDS ----
         {
             const float ds = a.ds1;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int pb = k == 2 ? pb2 : q + 4 * k;
-                if (k == 2 && q == 3) continue;
-                const int p = pb * 32 + lx;
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1 && npb == 1) continue;
+                const int p = (pb0 + j) * 32 + lx;
                 const int hy = (int)(((unsigned)p * 1928u) >> 16), hx = p - hy * HW_;      // p / 34 for p < 2^11
                 const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
                 const bool inside = p < HPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 if (p < HPIX) {
                     char* const rec = T + p * TPS + kh * 8;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float4 bv = *(const float4*)(a.b1 + mbw * 32 + j * 8 + kh * 4);
-                        float v0 = acc1[k][j * 4 + 0] * ds + bv.x, v1 = acc1[k][j * 4 + 1] * ds + bv.y, v2 = acc1[k][j * 4 + 2] * ds + bv.z, v3 = acc1[k][j * 4 + 3] * ds + bv.w;
-                        v0 = (inside && v0 > 0.f) ? v0 : 0.f; v1 = (inside && v1 > 0.f) ? v1 : 0.f; v2 = (inside && v2 > 0.f) ? v2 : 0.f; v3 = (inside && v3 > 0.f) ? v3 : 0.f;
-                        half4 hi, lo; bn_split4(v0, v1, v2, v3, hi, lo);
-                        vmax = split_absmax4(vmax, v0, v1, v2, v3);
-                        char* const d = rec + (2 * mbw + (j >> 1)) * 64 + (j & 1) * 16;
-                        *(half4*)d = hi; *(half4*)(d + 32) = lo;
-                    }
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float4 bv = *(const float4*)(a.b1 + m * 32 + jj * 8 + kh * 4);
+                            float v0 = acc1[j][m][jj * 4 + 0] * ds + bv.x, v1 = acc1[j][m][jj * 4 + 1] * ds + bv.y, v2 = acc1[j][m][jj * 4 + 2] * ds + bv.z, v3 = acc1[j][m][jj * 4 + 3] * ds + bv.w;
+                            v0 = (inside && v0 > 0.f) ? v0 : 0.f; v1 = (inside && v1 > 0.f) ? v1 : 0.f; v2 = (inside && v2 > 0.f) ? v2 : 0.f; v3 = (inside && v3 > 0.f) ? v3 : 0.f;
+                            half4 hi, lo; bn_split4(v0, v1, v2, v3, hi, lo);
+                            vmax = split_absmax4(vmax, v0, v1, v2, v3);
+                            char* const d = rec + (2 * m + (jj >> 1)) * 64 + (jj & 1) * 16;
+                            *(half4*)d = hi; *(half4*)(d + 32) = lo;
+                        }
                 }
             }
         }
         __syncthreads();                                             // t1 complete
+        BN_TICK(2);                                                  // epilogue 1
         // =============================== phase 2: conv2 3x3 from t1 ===============================
         f32x16 acc2[2];
 #pragma unroll
@@ -218,33 +305,42 @@ __global__ __launch_bounds__(512, 2) void bneck_split_kernel(BneckArgs a)
             };
             load_a2(0, 0); load_a2(1, 1);
             const char* const tb = T + (q * HW_ + lx) * TPS + kh * 16;
+            half8 Bh[2][2], Bl[2][2];
+            auto read_b = [&](int slot, int c, int tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const char* p = tb + ((i * RH + ky) * HW_ + kx) * TPS + c * 64;
+                    Bh[slot][i] = *(const half8*)p; Bl[slot][i] = *(const half8*)(p + 32);
+                }
+            };
+            read_b(0, 0, 0);
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    const int bs = tap & 1;                 // (9 taps per chunk: slot 0 is re-filled at every chunk start, during the last tap, which reads slot 0 itself: see below)
                     load_a2((tap + 2) % 3, c * 9 + tap + 2);
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    half8 Bh[2], Bl[2];
+                    if (tap + 1 < 9) read_b(bs ^ 1, c, tap + 1);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const char* p = tb + ((i * 4 + ky) * HW_ + kx) * TPS + c * 64;
-                        Bh[i] = *(const half8*)p; Bl[i] = *(const half8*)(p + 32);
-                    }
+                    for (int i = 0; i < 2; ++i) acc2[i] = BN_MFMA((half8)A2h[tap % 3], Bh[bs][i], acc2[i]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acc2[i] = BN_MFMA((half8)A2h[tap % 3], Bh[i], acc2[i]);
+                    for (int i = 0; i < 2; ++i) acc2[i] = BN_MFMA((half8)A2h[tap % 3], Bl[bs][i], acc2[i]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acc2[i] = BN_MFMA((half8)A2h[tap % 3], Bl[i], acc2[i]);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) acc2[i] = BN_MFMA((half8)A2l[tap % 3], Bh[i], acc2[i]);
+                    for (int i = 0; i < 2; ++i) acc2[i] = BN_MFMA((half8)A2l[tap % 3], Bh[bs][i], acc2[i]);
+                    if (tap + 1 == 9) read_b(0, c + 1 < 4 ? c + 1 : c, 0);      // tap 8 used slot 0: its MFMAs are issued, the registers may be re-filled
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        p3_weights(0);
+        BN_TICK(3);                                                  // phase 2
         __syncthreads();                                             // every wave is done reading t1
         // ---- epilogue 2: t2 = relu(acc * ds2 + b2) -> LDS (over t1) ----
         {
             const float ds = a.ds2;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int row = q + 4 * i;
+                const int row = q + RH * i;
                 const bool inside = oy0 + row < a.H && ox0 + lx < a.W;
                 char* const rec = T + (row * TW + lx) * TPS + kh * 8;
 #pragma unroll
@@ -253,93 +349,65 @@ __global__ __launch_bounds__(512, 2) void bneck_split_kernel(BneckArgs a)
                     float v0 = acc2[i][j * 4 + 0] * ds + bv.x, v1 = acc2[i][j * 4 + 1] * ds + bv.y, v2 = acc2[i][j * 4 + 2] * ds + bv.z, v3 = acc2[i][j * 4 + 3] * ds + bv.w;
                     v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
                     half4 hi, lo; bn_split4(v0, v1, v2, v3, hi, lo);
-                    const float m = split_absmax4(vmax, v0, v1, v2, v3);
-                    vmax = inside ? m : vmax;
+                    const float mx = split_absmax4(vmax, v0, v1, v2, v3);
+                    vmax = inside ? mx : vmax;
                     char* const d = rec + (2 * mbw + (j >> 1)) * 64 + (j & 1) * 16;
                     *(half4*)d = hi; *(half4*)(d + 32) = lo;
                 }
             }
         }
         __syncthreads();                                             // t2 complete
-        // =============================== phase 3: conv3 1x1 64->256 in two passes of 128 channels, + residual, ReLU, store ===============================
+        BN_TICK(4);                                                  // epilogue 2 (+ barrier wait)
+        // =============================== phase 3: conv3 1x1 64->256 in four passes of 64 channels (this wave: 32 of them x 2 rows), + residual, ReLU, store ===============================
         {
             const float ds = a.ds3;
-            int pstrip[4], ppx[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = i * 64 + lane, px = e >> 3, u = e & 7;
-                pstrip[i] = px * 128 + ((u ^ (px & 7)) * 16);
-                ppx[i] = px | (u << 8);
-            }
             char* const sp = strip + lx * 128 + kh * 8;
             const int sw = (lx & 7) * 16;
             auto run_hi = [&](int j) -> char* { return sp + ((j * 32) ^ sw); };
             auto run_lo = [&](int j) -> char* { return sp + ((j * 32 + 16) ^ sw); };
             const char* const t2b = T + (q * TW + lx) * TPS + kh * 16;
-            for (int pass = 0; pass < 2; ++pass) {
-                const int mb0 = pass * 4 + mbw * 2;
-                // weight image 3: [chunk][hi | lo][8 blocks][lane][8]
-                u32x4 A3h[4][2], A3l[4][2];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+            for (int pass = 0; pass < 4; ++pass) {
+                const int cur = pass & 1;
+                if (pass + 1 < 4) p3_residual(cur ^ 1, pass + 1);      // the next pass' residual pieces travel under this pass
+                f32x16 acc3[2];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        A3h[c][m] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (unsigned)(((c * 2 + 0) * 8 + mb0 + m) * 1024 + lane * 16), 0, 0);
-                        A3l[c][m] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (unsigned)(((c * 2 + 1) * 8 + mb0 + m) * 1024 + lane * 16), 0, 0);
-                    }
-                f32x16 acc3[2][2];
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc3[m][i][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc3[i][r] = 0.f;
                 if (EAGLE_ABL_BNECK != 5) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         half8 Bh[2], Bl[2];
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            const char* p = t2b + (i * 4 * TW) * TPS + c * 64;
+                            const char* p = t2b + (i * RH * TW) * TPS + c * 64;
                             Bh[i] = *(const half8*)p; Bl[i] = *(const half8*)(p + 32);
                         }
 #pragma unroll
-                        for (int m = 0; m < 2; ++m)
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) {
-                                acc3[m][i] = BN_MFMA((half8)A3h[c][m], Bh[i], acc3[m][i]);
-                                acc3[m][i] = BN_MFMA((half8)A3h[c][m], Bl[i], acc3[m][i]);
-                                acc3[m][i] = BN_MFMA((half8)A3l[c][m], Bh[i], acc3[m][i]);
-                            }
+                        for (int i = 0; i < 2; ++i) {
+                            acc3[i] = BN_MFMA((half8)A3[c][0], Bh[i], acc3[i]);
+                            acc3[i] = BN_MFMA((half8)A3[c][0], Bl[i], acc3[i]);
+                            acc3[i] = BN_MFMA((half8)A3[c][1], Bh[i], acc3[i]);
+                        }
                     }
                 }
-                // piece e = i * 64 + lane of a block (one row of 32 pixels x 32 channels): pixel e / 8, 16-byte unit e % 8 (4 channel groups x (hi, lo), tensor order)
-                auto piece_off = [&](int blk, int i, int cs, int off) -> unsigned {      // blk = m * 2 + row index; cs / off in fp16 elements
-                    const int m = blk >> 1, ri = blk & 1;
-                    const int oy = oy0 + q + 4 * ri, ox = ox0 + (ppx[i] & 0xFF), u = ppx[i] >> 8;
-                    return (oy < a.H && ox < a.W) ? (unsigned)((((n * a.H + oy) * a.W + ox) * cs + off + (mb0 + m) * 64 + u * 8) * 2) : OOB;
-                };
-                u32x4 rres[4][4];
+                if (pass + 1 < 4) p3_weights(pass + 1);
 #pragma unroll
-                for (int blk = 0; blk < 4; ++blk)
+                for (int ri = 0; ri < 2; ++ri) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) rres[blk][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, EAGLE_ABL_BNECK == 3 ? OOB : piece_off(blk, i, a.rcs, a.roff), 0, 0);
-#pragma unroll
-                for (int blk = 0; blk < 4; ++blk) {
-                    const int m = blk >> 1, ri = blk & 1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) *(u32x4*)(strip + pstrip[i]) = rres[blk][i];
+                    for (int i = 0; i < 4; ++i) *(u32x4*)(strip + pstrip[i]) = rres[cur][ri][i];
                     float v[4][4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float4 bv = *(const float4*)(a.b3 + (mb0 + m) * 32 + j * 8 + kh * 4);
-                        v[j][0] = acc3[m][ri][j * 4 + 0] * ds + bv.x; v[j][1] = acc3[m][ri][j * 4 + 1] * ds + bv.y;
-                        v[j][2] = acc3[m][ri][j * 4 + 2] * ds + bv.z; v[j][3] = acc3[m][ri][j * 4 + 3] * ds + bv.w;
+                        const float4 bv = *(const float4*)(a.b3 + (pass * 2 + mbw) * 32 + j * 8 + kh * 4);
+                        v[j][0] = acc3[ri][j * 4 + 0] * ds + bv.x; v[j][1] = acc3[ri][j * 4 + 1] * ds + bv.y;
+                        v[j][2] = acc3[ri][j * 4 + 2] * ds + bv.z; v[j][3] = acc3[ri][j * 4 + 3] * ds + bv.w;
                         const half4 rh = *(const half4*)run_hi(j), rl = *(const half4*)run_lo(j);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[j][r] = ((float)rh[r] + (float)rl[r]) * SPLIT_RX + v[j][r];
                     }
-                    const bool inside = oy0 + q + 4 * ri < a.H && ox0 + lx < a.W;
+                    const bool inside = oy0 + q + RH * ri < a.H && ox0 + lx < a.W;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -351,12 +419,18 @@ __global__ __launch_bounds__(512, 2) void bneck_split_kernel(BneckArgs a)
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, EAGLE_ABL_BNECK == 3 ? OOB : piece_off(blk, i, a.ycs, a.yoff), 0, EAGLE_STORE_NT * 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_y[ri][i], (pass * 2 + mbw) * 128, EAGLE_STORE_NT * 2);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         split_report(a.sat, n, vmax);
+        BN_TICK(5);                                                  // phase 3
     }
+#if EAGLE_BNECK_TIMING
+    if (a.dbg != nullptr && tid == 0)
+        for (int k = 0; k < 8; ++k) a.dbg[blockIdx.x * 8 + k] = tacc[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -403,16 +477,27 @@ void bneck_launch(const BneckLaunch& L, hipStream_t s)
     a.w1 = L.w1; a.w2 = L.w2; a.w3 = L.w3; a.b1 = L.b1; a.b2 = L.b2; a.b3 = L.b3; a.ds1 = L.ds1; a.ds2 = L.ds2; a.ds3 = L.ds3;
     a.r = L.res.p; a.rcs = L.res.cs * 2; a.roff = L.res.off * 2;
     a.y = L.y.p; a.ycs = L.y.cs * 2; a.yoff = L.y.off * 2;
-    a.tiles_x = (a.W + BNK_TW - 1) / BNK_TW; a.tiles_y = (a.H + BNK_TH - 1) / BNK_TH;
+    // form: 0 = tile 8 x 32, one 8-wave workgroup per CU; 1 = tile 4 x 32, two 4-wave workgroups per CU (EAGLE_BNECK_FORM; read per launch: the parity tests switch it)
+    const char* fe = getenv("EAGLE_BNECK_FORM");
+    const int form = fe ? atoi(fe) : EAGLE_BNECK_FORM_DEFAULT;
+    const int th = form == 1 ? 4 : 8;
+    a.tiles_x = (a.W + BNK_TW - 1) / BNK_TW; a.tiles_y = (a.H + th - 1) / th;
     a.sat = L.sat_slot ? *L.sat_slot : nullptr;
+    a.dbg = L.dbg;
     const size_t lim = (size_t)1 << 31, px = (size_t)a.N * a.H * a.W;
     if (px * a.xcs * 2 >= lim || px * a.rcs * 2 >= lim || px * a.ycs * 2 >= lim)
         fail(EAGLE_E_INVALID, "fused bottleneck: a tensor of %d frames reaches 2 GiB (32-bit tensor offsets); use a smaller device batch", a.N);
-    ensure_max_dynamic_lds((const void*)bneck_split_kernel, BNK_LDS);
     const char* we = getenv("EAGLE_BNECK_WGS");                     // (read per launch: the parity tests make several items share a workgroup)
-    const int wgs = we ? atoi(we) : 256;                            // one persistent workgroup per CU
     const int items = a.tiles_x * a.tiles_y * a.N;
-    hipLaunchKernelGGL(bneck_split_kernel, dim3(std::min(items, std::max(wgs, 8))), dim3(512), BNK_LDS, s, a);
+    if (form == 1) {
+        ensure_max_dynamic_lds((const void*)bneck_split_kernel<4, 1>, BneckGeom<4, 1>::LDS);
+        const int wgs = we ? atoi(we) : 512;                        // two persistent workgroups per CU
+        hipLaunchKernelGGL((bneck_split_kernel<4, 1>), dim3(std::min(items, std::max(wgs, 8))), dim3(256), (BneckGeom<4, 1>::LDS), s, a);
+    } else {
+        ensure_max_dynamic_lds((const void*)bneck_split_kernel<8, 2>, BneckGeom<8, 2>::LDS);
+        const int wgs = we ? atoi(we) : 256;                        // one persistent workgroup per CU
+        hipLaunchKernelGGL((bneck_split_kernel<8, 2>), dim3(std::min(items, std::max(wgs, 8))), dim3(512), (BneckGeom<8, 2>::LDS), s, a);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

@@ -93,6 +93,7 @@ struct BneckLaunch {
     const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;     // folded-BN biases
     float ds1 = 1.f, ds2 = 1.f, ds3 = 1.f;
     unsigned* const* sat_slot = nullptr;
+    unsigned long long* dbg = nullptr;       // developer timing builds only
 };
 bool bneck_supported(const TView& x, int cmid, int cout);
 // w: folded fp32 weights [taps][cin][cout] (taps = 1 or 9)
@@ -101,7 +102,7 @@ void bneck_launch(const BneckLaunch& L, hipStream_t s);
 
 // ---- other kernels ----------------------------------------------------------------------------------------
 struct LetterBox { int new_h, new_w, top, left, out_h, out_w; };
-LetterBox letterbox_geometry(int h, int w, int imgsz);
+LetterBox letterbox_geometry(int h, int w, int imgsz, int square = 0);      // square: EagleConfig::letterbox (auto=False)
 // which: bit 0 = write the key-point tensor, bit 1 = write the detector tensor; det_precision >= 0: the detector tensor's family when it differs from `precision`
 void preprocess_launch(int precision, const uint8_t* d_bgr, int n, int h, int w, const TView& kp, const TView& det,
                        const LetterBox& lb, hipStream_t s, int which = 3, int det_precision = -1);

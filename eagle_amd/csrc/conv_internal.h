@@ -38,6 +38,7 @@ struct BneckArgs {          // bneck.hip; channel strides / offsets in fp16 elem
     void* y; int ycs, yoff;
     int tiles_x, tiles_y;
     unsigned* sat;
+    unsigned long long* dbg;   // developer timing builds (-DEAGLE_BNECK_TIMING): per workgroup 8 accumulated s_memrealtime spans (100 MHz ticks), else unused
 };
 
 typedef void (*ConvKernel)(ConvArgs);

@@ -109,13 +109,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* bgr, int
     }
 }
 
-LetterBox letterbox_geometry(int h, int w, int imgsz)
+LetterBox letterbox_geometry(int h, int w, int imgsz, int square)
 {
-    // ultralytics LetterBox(new_shape=imgsz, auto=True, stride=32, center=True, scaleup=True)
+    // ultralytics LetterBox(new_shape=imgsz, auto=True, stride=32, center=True, scaleup=True); square: auto=False (the static imgsz x imgsz input of an exported
+    // ONNX detector, cm.py:54-55): the padding is NOT reduced modulo the stride
     const double r = std::min((double)imgsz / h, (double)imgsz / w);
     LetterBox lb;
     lb.new_w = (int)nearbyint(w * r); lb.new_h = (int)nearbyint(h * r);
-    double dw = (imgsz - lb.new_w) % 32, dh = (imgsz - lb.new_h) % 32;
+    double dw = square ? (imgsz - lb.new_w) : (imgsz - lb.new_w) % 32, dh = square ? (imgsz - lb.new_h) : (imgsz - lb.new_h) % 32;
     dw /= 2; dh /= 2;
     lb.top = (int)nearbyint(dh - 0.1); lb.left = (int)nearbyint(dw - 0.1);
     const int bottom = (int)nearbyint(dh + 0.1), right = (int)nearbyint(dw + 0.1);

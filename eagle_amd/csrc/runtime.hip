@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
@@ -52,33 +53,45 @@ static thread_local std::string g_create_error;
 // (hipMemcpy, hipMemset, a null-stream launch: hipErrorStreamCaptureImplicit) in every thread — also with a thread-local capture of non-blocking streams.  Small
 // batches capture by default since round 5, and a second handle on another host thread (the concurrency tests; a multi-handle server) uploads weights or runs an
 // operator on the null stream whenever it likes.  So a capture is made exclusive: every C-ABI entry holds this mutex shared for its duration (outermost call only),
-// the capturing thread trades its shared hold for the exclusive one around Begin ... EndCapture + instantiate (a few milliseconds, once per (slot, frame count)).
-static std::shared_mutex g_capture_mutex;
-static std::atomic<int> g_capture_waiting{0};      // threads queued for the exclusive hold: new API calls let them pass first (glibc's rwlock prefers readers; with
-                                                   // several handles making overlapping calls a capture could otherwise wait for ever)
-static thread_local std::shared_lock<std::shared_mutex>* t_api_lock = nullptr;
+// the capturing thread trades its shared hold for the exclusive one around Begin ... EndCapture + instantiate.
+// Round 6: the exclusive hold is only ever TRIED, for a bounded time (CAPTURE_TRY_MS).  Another handle's call may hold the mutex shared for seconds (a clip
+// call) or be blocked in a collective that waits for THIS thread's own gather (one thread per GPU in one process): waiting for it without a bound was a deadlock.
+// A capture that cannot get its turn is skipped — the step runs as plain launches, the same kernels in the same order — and tried again a few steps later.
+static std::shared_timed_mutex g_capture_mutex;
+static std::mutex g_gate_m;
+static std::condition_variable g_gate_cv;
+static int g_capture_waiting = 0;                  // threads queued for the exclusive hold: new API calls let them pass first (glibc's rwlock prefers readers; with
+                                                   // several handles making overlapping calls a capture would otherwise never get its turn), for a bounded time
+static constexpr int CAPTURE_TRY_MS = 10, GATE_WAIT_MS = 20;
+static thread_local std::shared_lock<std::shared_timed_mutex>* t_api_lock = nullptr;
 struct ApiGuard {
-    std::shared_lock<std::shared_mutex> lk;
+    std::shared_lock<std::shared_timed_mutex> lk;
     bool outer;
     ApiGuard() : lk(g_capture_mutex, std::defer_lock), outer(t_api_lock == nullptr)
     {
         if (!outer) return;
-        while (g_capture_waiting.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        {
+            std::unique_lock<std::mutex> g(g_gate_m);      // (a condition variable, not a spin: ADVICE r5)
+            g_gate_cv.wait_for(g, std::chrono::milliseconds(GATE_WAIT_MS), [] { return g_capture_waiting == 0; });
+        }
         lk.lock(); t_api_lock = &lk;
     }
     ~ApiGuard() { if (outer) t_api_lock = nullptr; }
 };
-struct CaptureExclusive {       // inside an API call: shared -> exclusive -> shared again
-    std::shared_lock<std::shared_mutex>* al;
-    std::unique_lock<std::shared_mutex> ex;
+struct CaptureExclusive {       // inside an API call: shared -> (try) exclusive -> shared again.  ok == false: no capture this time
+    std::shared_lock<std::shared_timed_mutex>* al;
+    std::unique_lock<std::shared_timed_mutex> ex;
+    bool ok = false;
     CaptureExclusive() : al(t_api_lock), ex(g_capture_mutex, std::defer_lock)
     {
         if (al && al->owns_lock()) al->unlock();
-        g_capture_waiting.fetch_add(1, std::memory_order_acq_rel);
-        ex.lock();
-        g_capture_waiting.fetch_sub(1, std::memory_order_acq_rel);
+        { std::lock_guard<std::mutex> g(g_gate_m); ++g_capture_waiting; }
+        ok = ex.try_lock_for(std::chrono::milliseconds(CAPTURE_TRY_MS));
+        { std::lock_guard<std::mutex> g(g_gate_m); --g_capture_waiting; }
+        g_gate_cv.notify_all();
+        if (!ok && al) al->lock();
     }
-    ~CaptureExclusive() { ex.unlock(); if (al) al->lock(); }
+    ~CaptureExclusive() { if (ok) { ex.unlock(); if (al) al->lock(); } }
 };
 static int g_dbg_skip = 0;      // developer bisection (eagle_debug "skip"): 1 HRNet, 2 detector, 4 decode + NMS, 8 geometry kernel, 16 preprocess, 32 heat-map maxima, 64 fuse_sum / pool / upsample ops, 128 convolutions
 
@@ -196,9 +209,13 @@ struct EagleHandle {
         uint8_t* h_frames = nullptr;         // pinned ring slot for caller frames that live in pageable memory (allocated on first use)
         bool copy_pending = false;           // ev_copy has been recorded for this slot
         hipEvent_t ev_compute = nullptr, ev_done = nullptr, ev_copy = nullptr;
-        hipGraphExec_t gexec = nullptr;
-        const uint8_t* g_src = nullptr; int g_n = 0;
+        // hipGraph instances of this slot's network phase, one per frame count (the source is always d_frames when graphs are on: a device-fed call is staged
+        // into it).  Round 5 kept ONE instance keyed on (source pointer, frame count): a call whose last step is ragged, or a caller walking a resident clip,
+        // re-captured (~80 ms, process-exclusive) on every call
+        std::map<int, hipGraphExec_t> graphs;
+        int capture_backoff = 0, capture_skip = 0;       // steps to run eagerly before the next capture attempt after one that could not get its turn
     } sb[2];
+    bool graph_broken = false;                           // a capture failed half-way: this handle runs plain launches from now on
     std::unique_ptr<Net> hr, yo, misc, reid;
     // K16 appearance embeddings (OSNet-x0.25; built when the "reid.*" tensors were loaded): REID_NB crops per pass
     TView reid_in; float* reid_feats = nullptr; EagleCrop* reid_crops = nullptr; EagleCrop* reid_crops_h = nullptr; float* reid_feats_h = nullptr;
@@ -895,37 +912,55 @@ static void enqueue_compute(EagleHandle* h, int p, const uint8_t* d_src, int n_a
 // profiles/r05c_latency_modes.txt).  Measured at batch 50, 20 steps: nothing on /opt/rocm's runtime (765.3 against 766.1 frames/s), +1.6 % on the PyTorch wheel's ROCm 7.0.2 runtime,
 // whose launch path is slower (739 -> 751): bench.py asks for 2 in its multi-rank path; "auto" stays at plain launches for batch > EAGLE_SMALL_BATCH (a capture costs ~80 ms per
 // (slot, frame count), which a short first call would pay inside its own latency)
-static bool graph_on(const EagleHandle* h) { return h->cfg.use_graph == 1 || (h->cfg.use_graph == 2 && h->call_steps >= 3); }
+static bool graph_on(const EagleHandle* h) { return !h->graph_broken && (h->cfg.use_graph == 1 || (h->cfg.use_graph == 2 && h->call_steps >= 3)); }
 
 static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_active)
 {
     const EagleConfig& c = h->cfg;
     EagleHandle::StepBuf& sb = h->sb[p];
+    bool replayed = false;
     if (graph_on(h) && !h->prof) {
         if (!h->warmed) {   // first call eager: lets every launcher set its function attributes outside a capture
             enqueue_compute(h, p, d_src, n_active);
             HIP_CHECK(hipStreamSynchronize(h->s_main));
             h->warmed = true;
         }
-        if (!sb.gexec || sb.g_src != d_src || sb.g_n != n_active) {
-            if (sb.gexec) { (void)hipGraphExecDestroy(sb.gexec); sb.gexec = nullptr; }
-            hipGraph_t g = nullptr;
+        if (d_src != sb.d_frames) fail(EAGLE_E_STATE, "graph replay needs the slot's staging buffer as the source");
+        auto it = sb.graphs.find(n_active);
+        if (it == sb.graphs.end() && sb.capture_skip > 0) --sb.capture_skip;
+        else if (it == sb.graphs.end()) {
             CaptureExclusive only_this_thread_talks_to_hip;
-            // thread-local capture mode: only THIS thread is held to capture-safe calls while the capture is open (it makes none: the warm-up step above has
-            // set every function attribute and allocated the zero / trash pages).  The global mode made every hipMalloc / hipFree / synchronise of ANY other
-            // thread fail with "operation not permitted when stream is capturing" — a second handle on another host thread, which is how the concurrency
-            // tests and a multi-handle server run — and left this stream in a broken capture (round 5: six tests of the suite, once small batches captured by default)
-            HIP_CHECK(hipStreamBeginCapture(h->s_main, hipStreamCaptureModeThreadLocal));
-            enqueue_compute(h, p, d_src, n_active);
-            HIP_CHECK(hipStreamEndCapture(h->s_main, &g));
-            HIP_CHECK(hipGraphInstantiate(&sb.gexec, g, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(g);
-            sb.g_src = d_src; sb.g_n = n_active;
+            if (only_this_thread_talks_to_hip.ok) {
+                // thread-local capture mode: only THIS thread is held to capture-safe calls while the capture is open (it makes none: the warm-up step above has
+                // set every function attribute and allocated the zero / trash pages).  The global mode made every hipMalloc / hipFree / synchronise of ANY other
+                // thread fail with "operation not permitted when stream is capturing" — a second handle on another host thread, which is how the concurrency
+                // tests and a multi-handle server run — and left this stream in a broken capture (round 5: six tests of the suite, once small batches captured by default)
+                struct CaptureScope {                       // a throw between Begin and End must not leave s_main capturing: end it, drop the graph, stop replaying
+                    EagleHandle* h; bool open = false; hipGraph_t g = nullptr;
+                    ~CaptureScope()
+                    {
+                        if (open) { (void)hipStreamEndCapture(h->s_main, &g); (void)hipGetLastError(); h->graph_broken = true; }
+                        if (g) (void)hipGraphDestroy(g);
+                    }
+                } cs{h};
+                HIP_CHECK(hipStreamBeginCapture(h->s_main, hipStreamCaptureModeThreadLocal));
+                cs.open = true;
+                enqueue_compute(h, p, d_src, n_active);
+                cs.open = false;
+                HIP_CHECK(hipStreamEndCapture(h->s_main, &cs.g));
+                hipGraphExec_t ge = nullptr;
+                if (hipGraphInstantiate(&ge, cs.g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); h->graph_broken = true; fail(EAGLE_E_HIP, "hipGraphInstantiate failed"); }
+                if (sb.graphs.size() >= 16) { (void)hipGraphExecDestroy(sb.graphs.begin()->second); sb.graphs.erase(sb.graphs.begin()); }      // (frame counts 1 .. batch: bounded)
+                it = sb.graphs.emplace(n_active, ge).first;
+                sb.capture_backoff = 0;
+            } else {
+                sb.capture_backoff = std::min(64, std::max(1, sb.capture_backoff * 2));
+                sb.capture_skip = sb.capture_backoff;
+            }
         }
-        HIP_CHECK(hipGraphLaunch(sb.gexec, h->s_main));
-    } else {
-        enqueue_compute(h, p, d_src, n_active);
+        if (it != sb.graphs.end()) { HIP_CHECK(hipGraphLaunch(it->second, h->s_main)); replayed = true; }
     }
+    if (!replayed) enqueue_compute(h, p, d_src, n_active);
     hipStream_t sp = h->prof ? h->s_main : h->s_post;
     if (!h->prof) {
         HIP_CHECK(hipEventRecord(sb.ev_compute, h->s_main));
@@ -1144,7 +1179,7 @@ static void finalize(EagleHandle* h)
     h->det_prec = c.det_precision ? c.det_precision - 1 : c.precision;
     h->hr.reset(new Net); h->yo.reset(new Net); h->misc.reset(new Net);
     const int cin_pad = h->prec == EAGLE_PREC_F32 ? 4 : 8, det_cin_pad = h->det_prec == EAGLE_PREC_F32 ? 4 : 8;
-    h->lb = letterbox_geometry(c.frame_h, c.frame_w, c.det_imgsz);
+    h->lb = letterbox_geometry(c.frame_h, c.frame_w, c.det_imgsz, c.letterbox);
     // inputs (written by the preprocess kernel)
     Builder Bh{h, h->hr.get(), h->prec, 1e-5, B};
     Builder By{h, h->yo.get(), h->det_prec, 1e-3, B};
@@ -1259,6 +1294,8 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     if (cfg->batch < 1 || cfg->frame_h < 32 || cfg->frame_w < 32) fail(EAGLE_E_INVALID, "bad batch/frame size");
     if (cfg->precision != EAGLE_PREC_F16 && cfg->precision != EAGLE_PREC_F32 && cfg->precision != EAGLE_PREC_F32S) fail(EAGLE_E_INVALID, "bad precision");
     if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
+    if (cfg->letterbox != EAGLE_LETTERBOX_RECT && cfg->letterbox != EAGLE_LETTERBOX_SQUARE) fail(EAGLE_E_INVALID, "letterbox: 0 (rect, auto=True) or 1 (square, auto=False)");
+    if (cfg->det_imgsz < 32 || cfg->det_imgsz % 32) fail(EAGLE_E_INVALID, "det_imgsz must be a positive multiple of 32 (the detector's largest stride)");
     if (cfg->det_precision < EAGLE_DET_PREC_AUTO || cfg->det_precision > EAGLE_PREC_F32S + 1) fail(EAGLE_E_INVALID, "bad detector precision");
     if (cfg->use_graph < EAGLE_AUTO || cfg->use_graph > 2 || cfg->multi_stream < EAGLE_AUTO || cfg->multi_stream > 1) fail(EAGLE_E_INVALID, "use_graph: -1 (auto), 0, 1 or 2; multi_stream: -1 (auto), 0 or 1");
     int ndev = 0;
@@ -1298,7 +1335,7 @@ void eagle_destroy(EagleHandle* h)
         h->comm = nullptr;
     }
     for (auto& sb : h->sb) {
-        if (sb.gexec) (void)hipGraphExecDestroy(sb.gexec);
+        for (auto& kv : sb.graphs) (void)hipGraphExecDestroy(kv.second);
         if (sb.h_sat) (void)hipHostFree(sb.h_sat);       // (h_out lies inside it)
         if (sb.h_frames) (void)hipHostFree(sb.h_frames);
         if (sb.ev_compute) (void)hipEventDestroy(sb.ev_compute);
@@ -1370,8 +1407,8 @@ int eagle_process_device_frames(EagleHandle* h, const void* d_bgr, int n, EagleF
     HIP_CHECK(hipSetDevice(h->cfg.device));
     const size_t fsz = (size_t)h->cfg.frame_h * h->cfg.frame_w * 3;
     h->call_steps = (n + h->cfg.batch - 1) / h->cfg.batch;
-    const bool direct = n <= h->cfg.batch || !graph_on(h);        // a multi-batch clip under graph replay goes through the
-    run_pipeline(h, n, out, [&](int p, int i, int na) -> const uint8_t* {   // stable staging pointer of its parity
+    const bool direct = !graph_on(h);                             // under graph replay every step goes through the stable staging pointer of its parity (a
+    run_pipeline(h, n, out, [&](int p, int i, int na) -> const uint8_t* {   // 2.76-MB-per-frame device copy; the instances are keyed by frame count alone)
         const uint8_t* src = (const uint8_t*)d_bgr + (size_t)i * fsz;
         if (direct) return src;
         HIP_CHECK(hipMemcpyAsync(h->sb[p].d_frames, src, fsz * na, hipMemcpyDeviceToDevice, h->s_main));
@@ -2074,8 +2111,17 @@ int eagle_op_bottleneck(int device, const float* x, int n, int h, int w, int cin
     bneck_tile_weights(w2, 9, 64, 64, img, &L.ds2); L.w2 = net.upload(img.data(), img.size() * 2);
     bneck_tile_weights(w3, 1, 64, 256, img, &L.ds3); L.w3 = net.upload(img.data(), img.size() * 2);
     L.b1 = (const float*)net.upload(b1, 64 * 4); L.b2 = (const float*)net.upload(b2, 64 * 4); L.b3 = (const float*)net.upload(b3, 256 * 4);
+    if (getenv("EAGLE_BNECK_TIMING")) L.dbg = (unsigned long long*)net.get(8192 * 8 * 8);      // (developer timing builds: -DEAGLE_BNECK_TIMING)
     bneck_launch(L, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
+    if (L.dbg) {
+        std::vector<unsigned long long> t(8192 * 8);
+        HIP_CHECK(hipMemcpy(t.data(), L.dbg, t.size() * 8, hipMemcpyDeviceToHost));
+        double sum[8] = {0}; int nw = 0;
+        for (int b = 0; b < 8192; ++b) { bool any = false; for (int k = 0; k < 8; ++k) { sum[k] += (double)t[b * 8 + k]; any |= t[b * 8 + k] != 0; } nw += any; }
+        if (nw) fprintf(stderr, "[bneck timing] %d workgroups, mean us per workgroup: phase1 %.1f  wait %.1f  epi1 %.1f  phase2 %.1f  epi2 %.1f  phase3 %.1f\n", nw,
+                        sum[0] / nw / 100, sum[1] / nw / 100, sum[2] / nw / 100, sum[3] / nw / 100, sum[4] / nw / 100, sum[5] / nw / 100);
+    }
     if (reps > 0 && ms) {                                   // developer timing: the launch alone, HIP events on the launch stream
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
@@ -2113,12 +2159,18 @@ int eagle_op_fuse_sum(int device, int precision, const float* base, int n, int H
 int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz,
                         float* kp_out, float* det_out, int* det_hw)
 {
+    return eagle_op_preprocess_lb(device, precision, bgr, n, h, w, det_imgsz, EAGLE_LETTERBOX_RECT, kp_out, det_out, det_hw);
+}
+
+int eagle_op_preprocess_lb(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz, int letterbox,
+                           float* kp_out, float* det_out, int* det_hw)
+{
     EagleHandle* hh = nullptr;
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
     Net net;
     const int cp = precision == EAGLE_PREC_F32 ? 4 : 8;
-    const LetterBox lb = letterbox_geometry(h, w, det_imgsz);
+    const LetterBox lb = letterbox_geometry(h, w, det_imgsz, letterbox);
     det_hw[0] = lb.out_h; det_hw[1] = lb.out_w;
     if (!kp_out || !det_out) return EAGLE_OK;
     uint8_t* d = (uint8_t*)net.upload(bgr, (size_t)n * h * w * 3);

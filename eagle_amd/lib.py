@@ -15,6 +15,7 @@ PREC_F16, PREC_F32, PREC_F32S = 0, 1, 2
 PRECISIONS = {"f16": PREC_F16, "f32": PREC_F32, "f32s": PREC_F32S}      # include/eagle.h EAGLE_PREC_*
 DET_VARIANTS = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
 AUTO, SMALL_BATCH, MULTI_STREAM_BATCH = -1, 8, 16                                              # include/eagle.h EAGLE_AUTO / EAGLE_SMALL_BATCH (use_graph: 0 off, 1 every step, 2 inside calls of >= 3 steps; multi_stream)
+LETTERBOX = {"rect": 0, "square": 1}                                    # include/eagle.h EAGLE_LETTERBOX_*: ultralytics LetterBox auto=True (the .pt predictor) / auto=False (the exported ONNX detector of cm.py:54-55)
 DET_PREC_AUTO = -1                                                     # include/eagle.h EAGLE_DET_PREC_AUTO
 
 
@@ -34,7 +35,7 @@ class EagleConfig(C.Structure):
                 ("keypoint_conf", C.c_double), ("detector_conf", C.c_double), ("ransac_thresh", C.c_double),
                 ("detector_floor", C.c_float), ("nms_iou", C.c_float),
                 ("ransac_max_iters", C.c_int32), ("lm_iters", C.c_int32), ("use_graph", C.c_int32), ("det_precision", C.c_int32),
-                ("allow_saturation", C.c_int32), ("multi_stream", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("allow_saturation", C.c_int32), ("multi_stream", C.c_int32), ("letterbox", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class EagleTimings(C.Structure):
@@ -130,6 +131,7 @@ def load():
     L.eagle_op_bottleneck.argtypes = [i32, fp, i32, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32, fp]
     L.eagle_op_fuse_sum.argtypes = [i32, i32, fp, i32, i32, i32, i32, i32, C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, fp]
     L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
+    L.eagle_op_preprocess_lb.argtypes = [i32, i32, u8p, i32, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
     L.eagle_op_find_homography.argtypes = [i32, fp, fp, i32, C.c_double, i32, i32, dp, u8p, C.POINTER(i32)]
     L.eagle_debug.argtypes = [C.c_char_p, i64, vp, i64]
     L.eagle_team_colors.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -192,6 +194,8 @@ def default_config(**kw):
     for k, v in kw.items():
         if k == "det_variant" and isinstance(v, str):
             v = DET_VARIANTS[v]
+        if k == "letterbox" and isinstance(v, str):
+            v = LETTERBOX[v]
         if not hasattr(cfg, k):
             raise TypeError(f"unknown config field {k}")
         setattr(cfg, k, v)
@@ -517,17 +521,17 @@ def op_fuse_sum(base, ups, relu=True, precision=PREC_F32, device=0):
     return y
 
 
-def op_preprocess(frames, det_imgsz=640, precision=PREC_F32, device=0):
+def op_preprocess(frames, det_imgsz=640, precision=PREC_F32, device=0, letterbox=0):
     L = load()
     frames = np.ascontiguousarray(frames, np.uint8)
     n, h, w, _ = frames.shape
     hw = (C.c_int * 2)()
-    rc = L.eagle_op_preprocess(device, precision, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, h, w, det_imgsz, None, None, hw)
+    rc = L.eagle_op_preprocess_lb(device, precision, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, h, w, det_imgsz, int(letterbox), None, None, hw)
     if rc:
         raise EagleError(f"eagle_op_preprocess failed ({rc}): {L.eagle_last_error(None).decode()}")
     kp = np.empty((n, 540, 960, 3), np.float32)
     det = np.empty((n, hw[0], hw[1], 3), np.float32)
-    rc = L.eagle_op_preprocess(device, precision, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, h, w, det_imgsz, _fp(kp), _fp(det), hw)
+    rc = L.eagle_op_preprocess_lb(device, precision, frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, h, w, det_imgsz, int(letterbox), _fp(kp), _fp(det), hw)
     if rc:
         raise EagleError(f"eagle_op_preprocess failed ({rc}): {L.eagle_last_error(None).decode()}")
     return kp, det

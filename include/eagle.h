@@ -48,6 +48,9 @@ extern "C" {
 #define EAGLE_MULTI_STREAM_BATCH 16 /* ... and steps of at most this many run HRNet's branches on their own streams (measured: +13 % at 12 and 16 frames, +2 % at 25, nothing at 50) */
 #define EAGLE_DET_PREC_AUTO (-1) /* EagleConfig::det_precision: chosen from `precision` by eagle_create */
 
+#define EAGLE_LETTERBOX_RECT 0
+#define EAGLE_LETTERBOX_SQUARE 1
+
 #define EAGLE_DET_N 0
 #define EAGLE_DET_S 1
 #define EAGLE_DET_M 2
@@ -85,7 +88,11 @@ typedef struct EagleConfig {
     int32_t multi_stream;      /* 1: HRNet's branches on their own HIP streams inside a step; 0: one stream per network; EAGLE_AUTO (default): 1 when
                                   batch <= EAGLE_MULTI_STREAM_BATCH or EAGLE_MULTI_STREAM is set in the environment (at large batches every launch fills the
                                   chip and the extra streams measure nothing) */
-    int32_t reserved[4];
+    int32_t letterbox;         /* detector input geometry (ultralytics LetterBox): EAGLE_LETTERBOX_RECT (0, default) = auto=True, what the .pt predictor
+                                  of cm.py:56-57 does — pad only to the next multiple of 32 (1280x720 @640 -> 384 x 640, 5040 anchors);
+                                  EAGLE_LETTERBOX_SQUARE (1) = auto=False, what the exported ONNX detector of the reference's CPU default runs with (cm.py:54-55,
+                                  detector_medium.onnx: a static det_imgsz x det_imgsz input — 1280x720 @640 -> 640 x 640, rows 140 / 140 of grey padding, 8400 anchors) */
+    int32_t reserved[3];
 } EagleConfig;
 
 typedef struct EagleDet {      /* one row of boxes.xyxy/.conf/.cls after NMS (cm.py:569-572) + cm.py:598-627 */
@@ -281,6 +288,8 @@ int eagle_op_fuse_sum(int device, int precision, const float* base, int n, int H
                       const float* const* ups, const int* up_h, const int* up_w, int relu, float* y);
 int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz,
                         float* kp_out /* n*540*960*3 */, float* det_out /* n*dh*dw*3 */, int* det_hw /* 2 */);
+int eagle_op_preprocess_lb(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz, int letterbox /* EAGLE_LETTERBOX_* */,
+                           float* kp_out, float* det_out, int* det_hw);
 int eagle_op_find_homography(int device, const float* img_pts, const float* world_pts, int n, double thresh,
                              int max_iters, int lm_iters, double* H9, uint8_t* mask, int* ok);
 

@@ -49,9 +49,11 @@ def letterbox_geometry(h, w, imgsz=640, stride=32, auto=True):
     return dict(new_w=new_w, new_h=new_h, top=top, left=left, out_h=new_h + top + bottom, out_w=new_w + left + right)
 
 
-def preprocess_detector(frame_bgr, imgsz=640):
+def preprocess_detector(frame_bgr, imgsz=640, auto=True):
+    """auto=True: the .pt predictor's LetterBox (pad to a multiple of 32; cm.py:56-57); auto=False: the static imgsz x imgsz input an exported ONNX detector
+    runs with (the reference's CPU default, cm.py:54-55 — ultralytics' AutoBackend sets auto = pt, i.e. False for .onnx)."""
     h, w = frame_bgr.shape[:2]
-    g = letterbox_geometry(h, w, imgsz)
+    g = letterbox_geometry(h, w, imgsz, auto=auto)
     rgb = np.ascontiguousarray(frame_bgr[:, :, ::-1])
     r = P.resize_linear_u8c3(rgb, g["new_h"], g["new_w"])
     canvas = np.full((g["out_h"], g["out_w"], 3), 114, np.uint8)

@@ -14,8 +14,10 @@ class OracleModel:
     'torch' (fast, MKLDNN order)."""
 
     def __init__(self, hrnet_sd, yolo_sd, variant="n", imgsz=640, backend="c", f16=False,
-                 keypoint_conf=0.3, detector_conf=0.35):
+                 keypoint_conf=0.3, detector_conf=0.35, letterbox="rect"):
         self.hr_sd, self.yo_sd, self.variant, self.imgsz = hrnet_sd, yolo_sd, variant, imgsz
+        assert letterbox in ("rect", "square")
+        self.letterbox_auto = letterbox == "rect"      # "square": LetterBox(auto=False), the exported ONNX detector's static input (cm.py:54-55)
         self.backend, self.f16 = backend, f16
         self.keypoint_conf, self.detector_conf = keypoint_conf, detector_conf
         self._hp = nets.Params(hrnet_sd, 1e-5, f16 and backend == "c")
@@ -24,7 +26,7 @@ class OracleModel:
     # cm.py:557-628
     def detect_objects(self, frame):
         h, w = frame.shape[:2]
-        x, g = host.preprocess_detector(frame, self.imgsz)
+        x, g = host.preprocess_detector(frame, self.imgsz, auto=self.letterbox_auto)
         heads = nets.yolo_heads(self.yo_sd, x, self.variant, self.backend, self.f16, self._yp)
         rows = nets.yolo_decode(heads)
         dets = host.nms_and_scale(rows, h, w, g["out_h"], g["out_w"], conf_thres=min(self.detector_conf, 0.15))

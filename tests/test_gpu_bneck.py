@@ -31,14 +31,16 @@ def _oracle(x, ws, res):
 SHAPES = [(1, 8, 32), (2, 19, 45), (3, 1, 1), (1, 7, 65), (5, 17, 30), (1, 9, 33), (2, 16, 64)]
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
 @pytest.mark.parametrize("wgs", ["256", "8"])
 @pytest.mark.parametrize("cin", [256, 64, 16])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_fused_bottleneck_against_the_oracle(shape, cin, wgs, monkeypatch):
+def test_fused_bottleneck_against_the_oracle(shape, cin, wgs, form, monkeypatch):
     """Ragged maps, partial tiles in both directions, a 1 x 1 map, several tiles per workgroup (EAGLE_BNECK_WGS=8: the x ring runs on across items and the
     next tile's first chunks are requested under phases 2 / 3), the identity shortcut (Cin = 256) and a separate residual tensor (block 0: Cin = 64)."""
     from eagle_amd import lib
     monkeypatch.setenv("EAGLE_BNECK_WGS", wgs)
+    monkeypatch.setenv("EAGLE_BNECK_FORM", form)        # 0: tile 8 x 32, one 8-wave workgroup per CU; 1: tile 4 x 32, two 4-wave workgroups per CU, one-slot x ring
     n, h, w = shape
     x = _rand((n, h, w, cin), 71)
     ws = _weights(cin, 72)
@@ -49,12 +51,14 @@ def test_fused_bottleneck_against_the_oracle(shape, cin, wgs, monkeypatch):
     assert err < BNECK_TOL, f"fused bottleneck error {err}"
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
 @pytest.mark.parametrize("cin", [256, 64])
-def test_fused_bottleneck_full_map_against_the_unfused_launches(cin, monkeypatch):
+def test_fused_bottleneck_full_map_against_the_unfused_launches(cin, form, monkeypatch):
     """One 135 x 240 frame (HRNet's layer-1 map: 17 x 8 tiles, the last tile row one pixel row short, the last column half empty) with 17 tiles per workgroup,
     against the three launches the kernel replaces (same family, same rounding of t1 / t2 to the split format) and against the oracle."""
     from eagle_amd import lib
     monkeypatch.setenv("EAGLE_BNECK_WGS", "8")
+    monkeypatch.setenv("EAGLE_BNECK_FORM", form)
     x = np.maximum(_rand((1, 135, 240, cin), 81), 0)          # post-ReLU activations, as in the network
     ws = _weights(cin, 82)
     w1, b1, w2, b2, w3, b3 = ws
@@ -69,10 +73,12 @@ def test_fused_bottleneck_full_map_against_the_unfused_launches(cin, monkeypatch
     assert np.abs(ref - got).max() / scale < BNECK_TOL
 
 
-def test_fused_bottleneck_zero_padding_of_the_intermediate():
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_fused_bottleneck_zero_padding_of_the_intermediate(form, monkeypatch):
     """conv2 pads t1 with ZEROS, not with relu(b1): a kernel that computed conv1 on the out-of-image halo and kept the result would differ on every border pixel.
     Large positive conv1 biases make that difference huge."""
     from eagle_amd import lib
+    monkeypatch.setenv("EAGLE_BNECK_FORM", form)
     x = _rand((1, 11, 37, 256), 91)
     w1, b1, w2, b2, w3, b3 = _weights(256, 92)
     b1 = np.abs(b1) + 3.0

@@ -139,6 +139,25 @@ def test_resize_and_letterbox_spec():
     assert x.shape == (1, 384, 640, 3) and x[0, 0, 0, 0] == np.float32(114) / np.float32(255) and x[0, 12, 0, 0] == 0
 
 
+def test_square_letterbox_of_the_exported_onnx_detector():
+    """LetterBox(auto=False): the reference's CPU default loads detector_medium.onnx (cm.py:54-55), whose static input ultralytics fills with a square letter-box
+    (AutoBackend: auto = pt, False for .onnx) — 1280 x 720 @640 -> 640 x 640, 140 grey rows above and below, 8400 anchors."""
+    from oracle import host
+    g = host.letterbox_geometry(720, 1280, 640, auto=False)
+    assert (g["out_h"], g["out_w"], g["top"], g["left"], g["new_h"], g["new_w"]) == (640, 640, 140, 0, 360, 640)
+    assert sum((640 // s) ** 2 for s in (8, 16, 32)) == 8400
+    g = host.letterbox_geometry(1080, 1920, 960, auto=False)
+    assert (g["out_h"], g["out_w"], g["top"]) == (960, 960, 210)
+    g = host.letterbox_geometry(500, 333, 320, auto=False)                  # portrait: the padding goes left and right
+    assert (g["out_h"], g["out_w"], g["top"], g["left"], g["new_w"]) == (320, 320, 0, 53, 213)
+    x, g = host.preprocess_detector(np.full((720, 1280, 3), 255, np.uint8), auto=False)
+    assert x.shape == (1, 640, 640, 3) and x[0, 139, 0, 0] == np.float32(114) / np.float32(255) and x[0, 140, 0, 0] == 1 and x[0, 499, 0, 0] == 1 and x[0, 500, 0, 0] != 1
+    # scale_boxes undoes it: a box in the padded input maps back with pad (0, 140), gain 0.5
+    rows = np.zeros((1, 9), np.float32); rows[0, :4] = (320, 320, 100, 50); rows[0, 4] = 0.9
+    d = host.nms_and_scale(rows, 720, 1280, 640, 640)
+    assert np.allclose(d[0, :4], [(270) / 0.5, (295 - 140) / 0.5, (370) / 0.5, (345 - 140) / 0.5])
+
+
 def test_boundaries_exceptions_become_none():
     from oracle import host
     assert host.boundaries(None, 720, 1280) == [None] * 4

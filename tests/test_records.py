@@ -106,3 +106,14 @@ def test_ingest_sampling_equals_reference_read_video():
     clip = np.arange(12 * 2 * 2 * 3, dtype=np.uint8).reshape(12, 2, 2, 3)
     frames, fps = eio.read_clip(clip, 50.0, 24)
     assert fps == 24 and frames.shape == (6, 2, 2, 3) and np.array_equal(frames, clip[::2])
+
+
+def test_coordinate_model_passes_the_graph_mode_through():
+    """EagleConfig::use_graph takes 0, 1 and 2 (replay only inside calls of >= 3 steps); the wrapper used to map everything through bool() (ADVICE r5)."""
+    import pytest
+    from eagle_amd import lib
+    from eagle_amd.coordinate_model import CoordinateModel
+    gm = CoordinateModel._graph_mode
+    assert gm(None) == lib.AUTO and gm(False) == 0 and gm(True) == 1 and gm(0) == 0 and gm(1) == 1 and gm(2) == 2
+    with pytest.raises(ValueError):
+        gm(3)

@@ -1,5 +1,5 @@
 """Developer probe: isolated duration of the fused Bottleneck launch (csrc/bneck.hip) at the bench's device batch.
-usage: python tools/probes/bneck_probe.py [batch=50] [reps=20]   ->  one line per Cin in {256, 64}"""
+usage: python tools/probes/bneck_probe.py [batch=50] [reps=20] [cins=256,64]   ->  one line per Cin"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -8,7 +8,8 @@ from eagle_amd import lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rng = np.random.default_rng(5)
-for cin in (256, 64):
+cins = [int(c) for c in sys.argv[3].split(",")] if len(sys.argv) > 3 else [256, 64]
+for cin in cins:
     x = np.maximum(rng.standard_normal((B, 135, 240, cin), dtype=np.float32), 0)
     w1 = (rng.standard_normal((1, 1, cin, 64)) * (2.0 / cin) ** 0.5).astype(np.float32)
     w2 = (rng.standard_normal((3, 3, 64, 64)) * (2.0 / 576) ** 0.5).astype(np.float32)
@@ -20,5 +21,5 @@ for cin in (256, 64):
     px = B * 135 * 240
     gb = px * 4.0 * (cin + 256 + (0 if res is None else 256)) / 1e9
     gf = px * 2.0 * (cin * 64 + 576 * 64 + 64 * 256) / 1e9
-    print(f"bneck Cin={cin} B={B}: {ms * 1e3:.1f} us per launch  algorithmic {gb:.2f} GB -> {gb / ms:.0f} GB/s, {gf / ms:.0f} GFLOP/ms  (wall {time.time() - t0:.1f} s, |y| max {np.abs(y).max():.3f})", flush=True)
+    print(f"bneck Cin={cin} B={B}: {ms * 1e3:.1f} us per launch  algorithmic {gb:.2f} GB -> {gb / ms:.2f} TB/s, {gf / ms:.0f} TFLOP/s  (wall {time.time() - t0:.1f} s, |y| max {np.abs(y).max():.3f})", flush=True)
     del x, y, res

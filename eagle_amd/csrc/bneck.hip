@@ -176,6 +176,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         const int oy0 = ty * TH, ox0 = tx * TW;
         float vmax = 0.0f;
         // =============================== phase 1: conv1 over the halo (no barrier: every wave streams its own pixel blocks) ===============================
+        if (EAGLE_ABL_BNECK == 6 && item > item0) { issue_x(); if (NSLOT > 1 && nch1 > 1) issue_x(); }      // (developer ablation: no request crosses an item boundary)
         f32x16 acc1[2][2];                                  // [local pixel block][channel block]
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's fragment reads of the slot are complete ...
-            if (issued == g + NSLOT && issued < GC) issue_x();   // ... so chunk g + NSLOT may land in it
+            if (issued == g + NSLOT && issued < GC && !(EAGLE_ABL_BNECK == 6 && ch + NSLOT >= nch1)) issue_x();   // ... so chunk g + NSLOT may land in it
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                 if (pass + 1 < 4) p3_weights(pass + 1);
 #pragma unroll
                 for (int ri = 0; ri < 2; ++ri) {
+                    if (EAGLE_ABL_BNECK == 8) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) *(u32x4*)(strip + pstrip[i]) = rres[cur][ri][i];
                     float v[4][4];
@@ -420,11 +422,19 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_y[ri][i], (pass * 2 + mbw) * 128, EAGLE_STORE_NT * 2);
+                    // HAZARD (found the hard way, round 6): a buffer_store of more than 64 bits reads its data VGPRs a few cycles AFTER it issues; a VALU write to
+                    // one of them in the next issue slot corrupts the stored dword in some lanes.  hipcc's hazard recognizer inserts the wait state only when the
+                    // store's soffset is an immediate — these stores carry the pass' channel block in an SGPR soffset, for which it assumes no hazard — and on gfx950 the
+                    // corruption does happen once the CU's VMEM issue is back-pressured (two co-resident workgroups: 1 - 2 thousand wrong values per 66 M at B = 8,
+                    // always the first dword of the item's LAST store, which the epilogue's v_cndmask on the saturation maximum overwrote; tools/probes/bneck_debug.py,
+                    // tests/test_gpu_bneck.py::test_fused_bottleneck_forms_agree_with_co_resident_workgroups).  Three explicit wait states behind every block's stores.
+                    asm volatile("s_nop 2" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         split_report(a.sat, n, vmax);
+        if (EAGLE_ABL_BNECK == 7) __syncthreads();
         BN_TICK(5);                                                  // phase 3
     }
 #if EAGLE_BNECK_TIMING
@@ -492,7 +502,10 @@ void bneck_launch(const BneckLaunch& L, hipStream_t s)
     if (form == 1) {
         ensure_max_dynamic_lds((const void*)bneck_split_kernel<4, 1>, BneckGeom<4, 1>::LDS);
         const int wgs = we ? atoi(we) : 512;                        // two persistent workgroups per CU
-        hipLaunchKernelGGL((bneck_split_kernel<4, 1>), dim3(std::min(items, std::max(wgs, 8))), dim3(256), (BneckGeom<4, 1>::LDS), s, a);
+        const char* pe = getenv("EAGLE_BNECK_LDS_PAD");             // developer: extra LDS bytes per workgroup (forces ONE workgroup per CU)
+        const int pad = pe ? atoi(pe) : 0;
+        if (pad) ensure_max_dynamic_lds((const void*)bneck_split_kernel<4, 1>, BneckGeom<4, 1>::LDS + pad);
+        hipLaunchKernelGGL((bneck_split_kernel<4, 1>), dim3(std::min(items, std::max(wgs, 8))), dim3(256), (BneckGeom<4, 1>::LDS) + pad, s, a);
     } else {
         ensure_max_dynamic_lds((const void*)bneck_split_kernel<8, 2>, BneckGeom<8, 2>::LDS);
         const int wgs = we ? atoi(we) : 256;                        // one persistent workgroup per CU

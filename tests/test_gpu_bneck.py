@@ -85,3 +85,21 @@ def test_fused_bottleneck_zero_padding_of_the_intermediate(form, monkeypatch):
     ref = _oracle(x, (w1, b1, w2, b2, w3, b3), None)
     got = lib.op_bottleneck(x, w1, b1, w2, b2, w3, b3)
     assert np.abs(ref - got).max() / np.abs(ref).max() < BNECK_TOL
+
+
+def test_fused_bottleneck_forms_agree_with_co_resident_workgroups(monkeypatch):
+    """Eight 135 x 240 frames: 2176 tiles of the 4 x 32 form on 512 workgroups — TWO co-resident workgroups per CU, several tiles each — against the 8 x 32 form.  Both
+    forms accumulate every output in the same order, so the results must be identical bit for bit.  This is the configuration that exposed the store-data hazard of
+    csrc/bneck.hip (a VALU write to a wide store's data register in the issue slot behind it: 1 - 2 thousand corrupted values per run before the explicit wait states);
+    small maps and one workgroup per CU never showed it.  Three repetitions: the corruption was timing-dependent."""
+    from eagle_amd import lib
+    x = np.maximum(_rand((8, 135, 240, 256), 95), 0)
+    ws = _weights(256, 96)
+    monkeypatch.setenv("EAGLE_BNECK_FORM", "0")
+    y0 = lib.op_bottleneck(x, *ws)
+    assert np.isfinite(y0).all()
+    monkeypatch.setenv("EAGLE_BNECK_FORM", "1")
+    for wgs in ("512", "1024", "512"):
+        monkeypatch.setenv("EAGLE_BNECK_WGS", wgs)
+        y1 = lib.op_bottleneck(x, *ws)
+        assert np.array_equal(y0, y1), f"form 1 ({wgs} workgroups) differs from form 0 in {int((y0 != y1).sum())} values"

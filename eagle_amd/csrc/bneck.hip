@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -163,11 +164,24 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         ++issued;
         if (++r_ch == nch1) { r_ch = 0; ++r_item; if (r_item < item_end) req_origin(r_item); }
     };
+    // weight image 1: [chunk][hi | lo][2 blocks][lane][8]: 4 KiB per chunk.  A1[parity of the chunk inside its item][hi | lo][channel block]: the fragments of a chunk are
+    // requested right BEHIND that chunk's x requests, NSLOT chunks ahead of their use, into registers with static names (no rotation copies: hipcc waits at a copy, not
+    // at the use, and — the counter being in-order — with it for every older request)
+    u32x4 A1[2][2][2];
+    auto load_a1 = [&](auto PAR, int chunk) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) A1[PAR][pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, (unsigned)(lane * 16 + (pt * 2 + m) * 1024), (unsigned)(chunk * 4096), 0);
+    };
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1c{};
     req_origin(item0);
     issue_x();
     if (NSLOT > 1 && GC > 1) issue_x();
+    __builtin_amdgcn_sched_barrier(0);
 
-    const unsigned wlane = (unsigned)(lane * 16), w1lane = (unsigned)(mbw * 1024 + lane * 16);
+    const unsigned w1lane = (unsigned)(mbw * 1024 + lane * 16);
 #if EAGLE_BNECK_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -176,51 +190,54 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         const int oy0 = ty * TH, ox0 = tx * TW;
         float vmax = 0.0f;
         // =============================== phase 1: conv1 over the halo (no barrier: every wave streams its own pixel blocks) ===============================
-        if (EAGLE_ABL_BNECK == 6 && item > item0) { issue_x(); if (NSLOT > 1 && nch1 > 1) issue_x(); }      // (developer ablation: no request crosses an item boundary)
+        // accumulators start at bias / descale (the host passes the biases pre-multiplied by the exact power of two): no bias load in any epilogue
+        // (the fragments of the item's first two chunks are requested here, not across the item boundary: 32 registers that would otherwise live through phases 2 / 3)
+        load_a1(P0, 0);
+        load_a1(P1c, nch1 > 1 ? 1 : 0);
         f32x16 acc1[2][2];                                  // [local pixel block][channel block]
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[j][m][r] = 0.f;
-        // weight image 1: [chunk][hi | lo][2 blocks][lane][8]: 4 KiB per chunk
-        u32x4 A1[2][2];                                     // [hi | lo][channel block]
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) A1[pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, wlane + (pt * 2 + m) * 1024, 0, 0);
-        for (int ch = 0; ch < nch1; ++ch, ++g) {
-            // chunk g has landed: everything older than the requests of chunk g + 1 (3 or 5 per wave) is complete.  The first chunk of an item waits for
-            // everything (output stores of the previous item may still be in flight: stores and loads share the counter)
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 bv = *(const float4*)(a.b1 + m * 32 + jj * 8 + kh * 4);
+                acc1[0][m][jj * 4 + 0] = bv.x; acc1[0][m][jj * 4 + 1] = bv.y; acc1[0][m][jj * 4 + 2] = bv.z; acc1[0][m][jj * 4 + 3] = bv.w;
+            }
+            acc1[1][m] = acc1[0][m];
+        }
+        auto p1_body = [&](auto PAR, int ch) {
+            // chunk g and its weight fragments have landed: everything older than the requests of chunk g + 1 (3 or 5 x requests + 4 fragment loads per wave) is
+            // complete.  The first chunk of an item waits for everything (output stores of the previous item may still be in flight: stores and loads share the counter)
+            // (the request behind the item's LAST chunk carries no fragment loads: the next item loads its own)
             if (NSLOT == 1 || ch == 0 || issued != g + 2) __builtin_amdgcn_s_waitcnt(0x0F70);
-            else if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F75);
-            else __builtin_amdgcn_s_waitcnt(0x0F73);
-            const unsigned son = (unsigned)((ch + 1 < nch1 ? ch + 1 : ch) * 4096);
-            u32x4 A1n[2][2];
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) A1n[pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, wlane + (pt * 2 + m) * 1024, son, 0);
+            else if (ch + 1 >= nch1) { if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F75); else __builtin_amdgcn_s_waitcnt(0x0F73); }
+            else if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F79);
+            else __builtin_amdgcn_s_waitcnt(0x0F77);
+            __builtin_amdgcn_sched_barrier(0);
             const char* hb = Xw + (g % NSLOT) * XB + lx * PS + kh * 16;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j == 0 || npb == 2) {
-                const half8 Bh = *(const half8*)(hb + j * PBB), Bl = *(const half8*)(hb + j * PBB + 32);
+                    const half8 Bh = *(const half8*)(hb + j * PBB), Bl = *(const half8*)(hb + j * PBB + 32);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    acc1[j][m] = BN_MFMA((half8)A1[0][m], Bh, acc1[j][m]);
-                    acc1[j][m] = BN_MFMA((half8)A1[0][m], Bl, acc1[j][m]);
-                    acc1[j][m] = BN_MFMA((half8)A1[1][m], Bh, acc1[j][m]);
-                }
+                    for (int m = 0; m < 2; ++m) {
+                        acc1[j][m] = BN_MFMA((half8)A1[PAR][0][m], Bh, acc1[j][m]);
+                        acc1[j][m] = BN_MFMA((half8)A1[PAR][0][m], Bl, acc1[j][m]);
+                        acc1[j][m] = BN_MFMA((half8)A1[PAR][1][m], Bh, acc1[j][m]);
+                    }
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's fragment reads of the slot are complete ...
+            __builtin_amdgcn_sched_barrier(0);
             if (issued == g + NSLOT && issued < GC && !(EAGLE_ABL_BNECK == 6 && ch + NSLOT >= nch1)) issue_x();   // ... so chunk g + NSLOT may land in it
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) A1[pt][m] = A1n[pt][m];
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + 2 < nch1) load_a1(PAR, ch + 2);         // the chunk that meets these registers next
+            __builtin_amdgcn_sched_barrier(0);
+            ++g;
+        };
+        if (EAGLE_ABL_BNECK == 6 && item > item0) { issue_x(); if (NSLOT > 1 && nch1 > 1) issue_x(); }      // (developer ablation: no request crosses an item boundary)
+        for (int ch = 0; ch < nch1; ch += 2) {
+            p1_body(P0, ch);
+            if (ch + 1 < nch1) p1_body(P1c, ch + 1);
         }
         BN_TICK(0);                                                  // phase 1
         // residual pieces of phase 3's first pass: requested now, they travel under phase 2
@@ -245,6 +262,14 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         // are requested one pass ahead into the other half of a double buffer — those of pass 0 here, so that they travel under phase 2.
         // weight image 3: [chunk][hi | lo][8 blocks][lane][8]
         u32x4 A3[4][2], rres[2][2][4];
+        f32x16 acc3[2];                                     // block 0 is also where the pass' bias / descale lands (requested as soon as the previous pass has read it for the last time)
+        auto p3_bias = [&](int pass) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float4 bv = *(const float4*)(a.b3 + (pass * 2 + mbw) * 32 + jj * 8 + kh * 4);
+                acc3[0][jj * 4 + 0] = bv.x; acc3[0][jj * 4 + 1] = bv.y; acc3[0][jj * 4 + 2] = bv.z; acc3[0][jj * 4 + 3] = bv.w;
+            }
+        };
         auto p3_weights = [&](int pass) {                   // single buffer: requested right after the previous pass' MFMAs, they land under its epilogue
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -258,7 +283,15 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rres[buf][ri][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_r[ri][i], (pass * 2 + mbw) * 128, 0);
         };
-        p3_residual(0, 0);                                           // (they travel under phase 2)
+        f32x16 b2init;                                               // conv2's bias / descale in the accumulator layout: requested BEFORE the residual pieces (in-order counter:
+#pragma unroll                                                       // whatever is requested behind them waits for their HBM latency)
+        for (int jj = 0; jj < 4; ++jj) {
+            const float4 bv = *(const float4*)(a.b2 + mbw * 32 + jj * 8 + kh * 4);
+            b2init[jj * 4 + 0] = bv.x; b2init[jj * 4 + 1] = bv.y; b2init[jj * 4 + 2] = bv.z; b2init[jj * 4 + 3] = bv.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        p3_residual(0, 0);                                           // (they travel under epilogue 1 and phase 2)
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                             // every wave has left phase 3 of the previous item: the t1 region is free
         BN_TICK(1);                                                  // wait for the slowest wave
         // ---- epilogue 1: t1 = relu(acc * ds1 + b1), zero outside the image -> LDS ----
@@ -277,8 +310,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            const float4 bv = *(const float4*)(a.b1 + m * 32 + jj * 8 + kh * 4);
-                            float v0 = acc1[j][m][jj * 4 + 0] * ds + bv.x, v1 = acc1[j][m][jj * 4 + 1] * ds + bv.y, v2 = acc1[j][m][jj * 4 + 2] * ds + bv.z, v3 = acc1[j][m][jj * 4 + 3] * ds + bv.w;
+                            float v0 = acc1[j][m][jj * 4 + 0] * ds, v1 = acc1[j][m][jj * 4 + 1] * ds, v2 = acc1[j][m][jj * 4 + 2] * ds, v3 = acc1[j][m][jj * 4 + 3] * ds;
                             v0 = (inside && v0 > 0.f) ? v0 : 0.f; v1 = (inside && v1 > 0.f) ? v1 : 0.f; v2 = (inside && v2 > 0.f) ? v2 : 0.f; v3 = (inside && v3 > 0.f) ? v3 : 0.f;
                             half4 hi, lo; bn_split4(v0, v1, v2, v3, hi, lo);
                             vmax = split_absmax4(vmax, v0, v1, v2, v3);
@@ -293,9 +325,8 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         // =============================== phase 2: conv2 3x3 from t1 ===============================
         f32x16 acc2[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc2[0][r] = b2init[r];
+        acc2[1] = acc2[0];
         if (EAGLE_ABL_BNECK != 4) {
             // weight image 2: [chunk][tap][hi | lo][2 blocks][lane][8]: 4 KiB per (chunk, tap)
             u32x4 A2h[3], A2l[3];
@@ -333,7 +364,9 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                 }
             }
         }
-        p3_weights(0);
+        __builtin_amdgcn_sched_barrier(0);
+        p3_weights(0); p3_bias(0);
+        __builtin_amdgcn_sched_barrier(0);
         BN_TICK(3);                                                  // phase 2
         __syncthreads();                                             // every wave is done reading t1
         // ---- epilogue 2: t2 = relu(acc * ds2 + b2) -> LDS (over t1) ----
@@ -346,8 +379,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                 char* const rec = T + (row * TW + lx) * TPS + kh * 8;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 bv = *(const float4*)(a.b2 + mbw * 32 + j * 8 + kh * 4);
-                    float v0 = acc2[i][j * 4 + 0] * ds + bv.x, v1 = acc2[i][j * 4 + 1] * ds + bv.y, v2 = acc2[i][j * 4 + 2] * ds + bv.z, v3 = acc2[i][j * 4 + 3] * ds + bv.w;
+                    float v0 = acc2[i][j * 4 + 0] * ds, v1 = acc2[i][j * 4 + 1] * ds, v2 = acc2[i][j * 4 + 2] * ds, v3 = acc2[i][j * 4 + 3] * ds;
                     v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
                     half4 hi, lo; bn_split4(v0, v1, v2, v3, hi, lo);
                     const float mx = split_absmax4(vmax, v0, v1, v2, v3);
@@ -371,11 +403,8 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
             for (int pass = 0; pass < 4; ++pass) {
                 const int cur = pass & 1;
                 if (pass + 1 < 4) p3_residual(cur ^ 1, pass + 1);      // the next pass' residual pieces travel under this pass
-                f32x16 acc3[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc3[i][r] = 0.f;
+                __builtin_amdgcn_sched_barrier(0);                     // (pinned: hipcc otherwise sinks the requests to just in front of their use)
+                acc3[1] = acc3[0];
                 if (EAGLE_ABL_BNECK != 5) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -393,7 +422,9 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 if (pass + 1 < 4) p3_weights(pass + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ri = 0; ri < 2; ++ri) {
                     if (EAGLE_ABL_BNECK == 8) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
@@ -402,13 +433,13 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                     float v[4][4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float4 bv = *(const float4*)(a.b3 + (pass * 2 + mbw) * 32 + j * 8 + kh * 4);
-                        v[j][0] = acc3[ri][j * 4 + 0] * ds + bv.x; v[j][1] = acc3[ri][j * 4 + 1] * ds + bv.y;
-                        v[j][2] = acc3[ri][j * 4 + 2] * ds + bv.z; v[j][3] = acc3[ri][j * 4 + 3] * ds + bv.w;
+                        v[j][0] = acc3[ri][j * 4 + 0] * ds; v[j][1] = acc3[ri][j * 4 + 1] * ds;
+                        v[j][2] = acc3[ri][j * 4 + 2] * ds; v[j][3] = acc3[ri][j * 4 + 3] * ds;
                         const half4 rh = *(const half4*)run_hi(j), rl = *(const half4*)run_lo(j);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[j][r] = ((float)rh[r] + (float)rl[r]) * SPLIT_RX + v[j][r];
                     }
+                    if (ri == 1 && pass + 1 < 4) { __builtin_amdgcn_sched_barrier(0); p3_bias(pass + 1); __builtin_amdgcn_sched_barrier(0); }      // (the accumulators have been read for the last time)
                     const bool inside = oy0 + q + RH * ri < a.H && ox0 + lx < a.W;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -470,6 +501,13 @@ void bneck_tile_weights(const float* w, int taps, int cin, int cout, std::vector
                             const _Float16 hi = (_Float16)v;
                             *d++ = part == 0 ? hi : (_Float16)(v - (float)hi);
                         }
+}
+
+// The kernel starts its accumulators at bias / descale: descale is an exact power of two, so (sum + bias / descale) * descale == sum * descale + bias up to the rounding
+// of the accumulation itself; no epilogue loads a bias.
+void bneck_scale_bias(std::vector<float>& b, float descale)
+{
+    for (float& v : b) v = v / descale;
 }
 
 bool bneck_supported(const TView& x, int cmid, int cout)

@@ -90,7 +90,7 @@ ConvConfig conv_choose(int precision, int ks, int stride, int cin_pad, int cout_
 struct BneckLaunch {
     TView x, res, y;         // res: the 256-channel residual operand (x itself for an identity shortcut)
     const void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;      // fragment-major weight images (bneck_tile_weights)
-    const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;     // folded-BN biases
+    const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;     // folded-BN biases DIVIDED by the layer's descale (bneck_scale_bias): the accumulators' initial values
     float ds1 = 1.f, ds2 = 1.f, ds3 = 1.f;
     unsigned* const* sat_slot = nullptr;
     unsigned long long* dbg = nullptr;       // developer timing builds only
@@ -98,6 +98,7 @@ struct BneckLaunch {
 bool bneck_supported(const TView& x, int cmid, int cout);
 // w: folded fp32 weights [taps][cin][cout] (taps = 1 or 9)
 void bneck_tile_weights(const float* w, int taps, int cin, int cout, std::vector<_Float16>& out, float* descale);
+void bneck_scale_bias(std::vector<float>& b, float descale);      // b /= descale (exact: a power of two): what BneckLaunch::b1 / b2 / b3 must hold
 void bneck_launch(const BneckLaunch& L, hipStream_t s);
 
 // ---- other kernels ----------------------------------------------------------------------------------------

@@ -414,6 +414,7 @@ struct Builder {
             if (ks != want_ks[k] || ci != want_ci[k] || co != want_co[k]) fail(EAGLE_E_INVALID, "%s%s: not the Bottleneck shape of the fused kernel", q.c_str(), cn[k]);
             float ds = 1.f;
             bneck_tile_weights(hw.data(), ks * ks, ci, co, img, &ds);
+            bneck_scale_bias(bs, ds);
             const void* dw = net->upload(img.data(), img.size() * 2);
             const float* db = (const float*)net->upload(bs.data(), bs.size() * 4);
             if (k == 0) { L.w1 = dw; L.b1 = db; L.ds1 = ds; } else if (k == 1) { L.w2 = dw; L.b2 = db; L.ds2 = ds; } else { L.w3 = dw; L.b3 = db; L.ds3 = ds; }
@@ -2110,7 +2111,9 @@ int eagle_op_bottleneck(int device, const float* x, int n, int h, int w, int cin
     bneck_tile_weights(w1, 1, cin, 64, img, &L.ds1); L.w1 = net.upload(img.data(), img.size() * 2);
     bneck_tile_weights(w2, 9, 64, 64, img, &L.ds2); L.w2 = net.upload(img.data(), img.size() * 2);
     bneck_tile_weights(w3, 1, 64, 256, img, &L.ds3); L.w3 = net.upload(img.data(), img.size() * 2);
-    L.b1 = (const float*)net.upload(b1, 64 * 4); L.b2 = (const float*)net.upload(b2, 64 * 4); L.b3 = (const float*)net.upload(b3, 256 * 4);
+    std::vector<float> sb1(b1, b1 + 64), sb2(b2, b2 + 64), sb3(b3, b3 + 256);
+    bneck_scale_bias(sb1, L.ds1); bneck_scale_bias(sb2, L.ds2); bneck_scale_bias(sb3, L.ds3);
+    L.b1 = (const float*)net.upload(sb1.data(), 64 * 4); L.b2 = (const float*)net.upload(sb2.data(), 64 * 4); L.b3 = (const float*)net.upload(sb3.data(), 256 * 4);
     if (getenv("EAGLE_BNECK_TIMING")) L.dbg = (unsigned long long*)net.get(8192 * 8 * 8);      // (developer timing builds: -DEAGLE_BNECK_TIMING)
     bneck_launch(L, nullptr);
     HIP_CHECK(hipDeviceSynchronize());

@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -91,10 +92,41 @@ struct BneckGeom {
     static_assert(N2 >= 0 && N2 <= NW && LDS <= 160 * 1024, "geometry");
 };
 
-template <int TH, int NSLOT>
+// s_waitcnt immediate: vmcnt(n), expcnt and lgkmcnt untouched
+__host__ __device__ constexpr unsigned bn_vmcnt(int n) { return 0x0F70u | (unsigned)((n > 63 ? 63 : n) & 15) | ((unsigned)((n > 63 ? 63 : n) >> 4) << 14); }
+// Phase 1 with the DEEP ring (NCH = the compile-time number of 16-channel chunks, 16 or 4): the t1 / t2 / strip region is idle while conv1 streams x, so three more ring
+// slots live there (NR = 3) next to the ND dedicated ones: D = ND + NR chunks deep.  Chunk ch of an item lives in slot ch % D (slots below ND: dedicated).  Per wave and item
+// the request sequence is   S: fragments of chunks 0 .. ND - 1, 8 bias loads | barrier "region free" | E(ND) .. E(D - 1) | body(0) X(0) body(1) X(1) ...
+// with E(c) = the wave's npi x requests of chunk c followed by its 4 fragment loads, X(k) = E(k + D) if that chunk exists, else — when slot k % D is a dedicated one
+// and the workgroup has a next item — the npi x requests of the NEXT item's chunk k % D (its fragments are loaded at that item's start).  bn_p1_after = the number
+// of vector-memory operations the wave has issued behind the fragments of chunk ch when body(ch) starts: the vmcnt literal that says "chunk ch and its
+// fragments have landed" without waiting for anything younger (the counter is in-order).
+template <int D, int ND, int NCH>
+__host__ __device__ constexpr int bn_p1_after(int ch, int npi, bool has_next)
+{
+    int n = 0;
+    const int nd = ND < NCH ? ND : NCH;
+    if (ch < nd) {
+        n += (nd - 1 - ch) * 4 + 8;
+        for (int c = ND; c < D && c < NCH; ++c) n += npi + 4;
+        for (int k = 0; k < ch; ++k) n += k + D < NCH ? npi + 4 : ((k % D) < ND && has_next ? npi : 0);
+    } else if (ch < D) {
+        for (int c = ch + 1; c < D && c < NCH; ++c) n += npi + 4;
+        for (int k = 0; k < ch; ++k) n += k + D < NCH ? npi + 4 : ((k % D) < ND && has_next ? npi : 0);
+    } else {
+        for (int k = ch - D + 1; k < ch; ++k) n += k + D < NCH ? npi + 4 : ((k % D) < ND && has_next ? npi : 0);
+    }
+    return n;
+}
+template <class F, int... I>
+__device__ __forceinline__ void bn_for_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+template <int TH, int NSLOT, int NCH>
 __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
 {
     using G = BneckGeom<TH, NSLOT>;
+    constexpr int ND = NSLOT, NR = NCH > 0 ? 3 : 0, D = ND + NR;      // ring depth of phase 1 (NCH = 0: the generic form, dedicated slots only, any number of chunks)
+    static_assert(NR * G::XB <= G::REG, "the region slots fit the t1 region");
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int TW = BNK_TW, HW_ = BNK_HW, HPIX = G::HPIX, PS = BNK_PS, PBB = BNK_PBB, XB = G::XB, TPS = BNK_TPS, RH = TH / 2, N2 = G::N2;
@@ -164,6 +196,39 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         ++issued;
         if (++r_ch == nch1) { r_ch = 0; ++r_item; if (r_item < item_end) req_origin(r_item); }
     };
+    // ---- requests of one chunk with explicit geometry (deep ring: the order of requests is not the order of the chunks) ----
+    struct Geo { int iy0, ix0, gb; };
+    auto geo_of = [&](int item) -> Geo {
+        int n, ty, tx; decode(item, n, ty, tx);
+        Geo q_; q_.iy0 = ty * TH - 1; q_.ix0 = tx * TW - 1;
+        q_.gb = (((n * a.H + q_.iy0) * a.W + q_.ix0) * a.xcs + a.xoff) * 2;
+        return q_;
+    };
+    auto issue_chunk = [&](const Geo& ge, int c, char* dst) {
+        const unsigned so = (unsigned)(c * 64);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (k >= 3 && npb == 1) continue;              // (wave-uniform)
+            const int hy = hpk[k] & 0xFF, hx = (hpk[k] >> 8) & 0xFF, unit = (hpk[k] >> 16) & 7;
+            const int iy = ge.iy0 + hy, ix = ge.ix0 + hx;
+            const unsigned off = !(hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? OOB
+                                 : (unsigned)(ge.gb + ((hy * a.W + hx) * a.xcs + unit * 8) * 2);
+            if (hpk[k] != -2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, EAGLE_ABL_BNECK == 1 ? OOB : off, so, 0, 0);
+        }
+    };
+    char* const Rw = smem + pb0 * PBB;                     // this wave's part of a REGION slot (+ region slot * XB)
+    auto slot_of = [&](int ch) -> char* { const int sl = ch % (D > 0 ? D : 1); return sl < ND ? Xw + sl * XB : Rw + (sl - ND) * XB; };
+    // fragment ring of the deep form: AD[chunk % D][hi | lo][channel block]
+    u32x4 AD[NCH > 0 ? D : 1][2][2];
+    auto load_ad = [&](auto CH) {
+        constexpr int c = decltype(CH)::value;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) AD[c % (D > 0 ? D : 1)][pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, (unsigned)(lane * 16 + (pt * 2 + m) * 1024), (unsigned)(c * 4096), 0);
+    };
+    Geo cur = geo_of(item0);
     // weight image 1: [chunk][hi | lo][2 blocks][lane][8]: 4 KiB per chunk.  A1[parity of the chunk inside its item][hi | lo][channel block]: the fragments of a chunk are
     // requested right BEHIND that chunk's x requests, NSLOT chunks ahead of their use, into registers with static names (no rotation copies: hipcc waits at a copy, not
     // at the use, and — the counter being in-order — with it for every older request)
@@ -176,11 +241,18 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
     };
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1c{};
-    req_origin(item0);
-    issue_x();
-    if (NSLOT > 1 && GC > 1) issue_x();
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NCH == 0) {
+        req_origin(item0);
+        issue_x();
+        if (NSLOT > 1 && GC > 1) issue_x();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < ND && c < NCH; ++c) issue_chunk(cur, c, slot_of(c));
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const unsigned w1lane = (unsigned)(mbw * 1024 + lane * 16);
 #if EAGLE_BNECK_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
@@ -191,10 +263,14 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         float vmax = 0.0f;
         // =============================== phase 1: conv1 over the halo (no barrier: every wave streams its own pixel blocks) ===============================
         // accumulators start at bias / descale (the host passes the biases pre-multiplied by the exact power of two): no bias load in any epilogue
-        // (the fragments of the item's first two chunks are requested here, not across the item boundary: 32 registers that would otherwise live through phases 2 / 3)
-        load_a1(P0, 0);
-        load_a1(P1c, nch1 > 1 ? 1 : 0);
         f32x16 acc1[2][2];                                  // [local pixel block][channel block]
+        if constexpr (NCH == 0) {
+            // (the fragments of the item's first two chunks are requested here, not across the item boundary: 32 registers that would otherwise live through phases 2 / 3)
+            load_a1(P0, 0);
+            load_a1(P1c, nch1 > 1 ? 1 : 0);
+        } else {
+            bn_for_seq(std::make_integer_sequence<int, (ND < NCH ? ND : NCH)>{}, [&](auto I_) { load_ad(I_); });
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -202,8 +278,54 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                 const float4 bv = *(const float4*)(a.b1 + m * 32 + jj * 8 + kh * 4);
                 acc1[0][m][jj * 4 + 0] = bv.x; acc1[0][m][jj * 4 + 1] = bv.y; acc1[0][m][jj * 4 + 2] = bv.z; acc1[0][m][jj * 4 + 3] = bv.w;
             }
-            acc1[1][m] = acc1[0][m];
+            if constexpr (NCH == 0) acc1[1][m] = acc1[0][m];      // (deep form: copied inside body 0, behind its wait)
         }
+        if constexpr (NCH > 0) {
+            // =========== deep ring: D = ND + 3 chunks, the three extra slots in the idle t1 region ===========
+            const bool has_next = item + 1 < item_end;
+            const Geo nxt = has_next ? geo_of(item + 1) : cur;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();                    // "region free": every wave has left phase 3 of the previous item (its strip reads fed stores that have issued)
+            __builtin_amdgcn_sched_barrier(0);
+            bn_for_seq(std::make_integer_sequence<int, (D < NCH ? D : NCH) - (ND < NCH ? ND : NCH)>{}, [&](auto I_) {
+                constexpr int c = decltype(I_)::value + ND;
+                issue_chunk(cur, c, slot_of(c));
+                __builtin_amdgcn_sched_barrier(0);
+                load_ad(std::integral_constant<int, c>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            bn_for_seq(std::make_integer_sequence<int, NCH>{}, [&](auto CH) {
+                constexpr int ch = decltype(CH)::value;
+                if (npb == 2) { if (has_next) __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 5, true))); else __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 5, false))); }
+                else { if (has_next) __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 3, true))); else __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 3, false))); }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ch == 0) { acc1[1][0] = acc1[0][0]; acc1[1][1] = acc1[0][1]; }      // (the bias loads are older than everything the wait above lets through)
+                const char* hb = slot_of(ch) + lx * PS + kh * 16;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j == 0 || npb == 2) {
+                        const half8 Bh = *(const half8*)(hb + j * PBB), Bl = *(const half8*)(hb + j * PBB + 32);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            acc1[j][m] = BN_MFMA((half8)AD[ch % D][0][m], Bh, acc1[j][m]);
+                            acc1[j][m] = BN_MFMA((half8)AD[ch % D][0][m], Bl, acc1[j][m]);
+                            acc1[j][m] = BN_MFMA((half8)AD[ch % D][1][m], Bh, acc1[j][m]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's fragment reads of the slot are complete
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ch + D < NCH) {
+                    issue_chunk(cur, ch + D, slot_of(ch));
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_ad(std::integral_constant<int, ch + D>{});
+                } else if constexpr ((ch % D) < ND) {
+                    if (has_next) issue_chunk(nxt, ch % D, slot_of(ch));      // the next item's chunk ch % D: the dedicated slot has seen its last chunk of this item
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            cur = nxt;
+        } else {
         auto p1_body = [&](auto PAR, int ch) {
             // chunk g and its weight fragments have landed: everything older than the requests of chunk g + 1 (3 or 5 x requests + 4 fragment loads per wave) is
             // complete.  The first chunk of an item waits for everything (output stores of the previous item may still be in flight: stores and loads share the counter)
@@ -238,6 +360,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         for (int ch = 0; ch < nch1; ch += 2) {
             p1_body(P0, ch);
             if (ch + 1 < nch1) p1_body(P1c, ch + 1);
+        }
         }
         BN_TICK(0);                                                  // phase 1
         // residual pieces of phase 3's first pass: requested now, they travel under phase 2
@@ -537,18 +660,22 @@ void bneck_launch(const BneckLaunch& L, hipStream_t s)
         fail(EAGLE_E_INVALID, "fused bottleneck: a tensor of %d frames reaches 2 GiB (32-bit tensor offsets); use a smaller device batch", a.N);
     const char* we = getenv("EAGLE_BNECK_WGS");                     // (read per launch: the parity tests make several items share a workgroup)
     const int items = a.tiles_x * a.tiles_y * a.N;
+    // ring: 1 (default) = the deep phase-1 ring where the kernel has a compile-time chunk count (Cin = 256: 16 chunks, Cin = 64: 4); 0 = the generic form for every Cin
+    const char* re = getenv("EAGLE_BNECK_RING");
+    const int nch = (re && atoi(re) == 0) ? 0 : (a.nch1 == 16 ? 16 : a.nch1 == 4 ? 4 : 0);
+    typedef void (*Kern)(BneckArgs);
+    const char* pe = getenv("EAGLE_BNECK_LDS_PAD");                 // developer: extra LDS bytes per workgroup (forces ONE workgroup per CU in form 1)
+    const int pad = pe ? atoi(pe) : 0;
+    Kern fn; int lds, threads, wgs;
     if (form == 1) {
-        ensure_max_dynamic_lds((const void*)bneck_split_kernel<4, 1>, BneckGeom<4, 1>::LDS);
-        const int wgs = we ? atoi(we) : 512;                        // two persistent workgroups per CU
-        const char* pe = getenv("EAGLE_BNECK_LDS_PAD");             // developer: extra LDS bytes per workgroup (forces ONE workgroup per CU)
-        const int pad = pe ? atoi(pe) : 0;
-        if (pad) ensure_max_dynamic_lds((const void*)bneck_split_kernel<4, 1>, BneckGeom<4, 1>::LDS + pad);
-        hipLaunchKernelGGL((bneck_split_kernel<4, 1>), dim3(std::min(items, std::max(wgs, 8))), dim3(256), (BneckGeom<4, 1>::LDS) + pad, s, a);
+        fn = nch == 16 ? (Kern)bneck_split_kernel<4, 1, 16> : nch == 4 ? (Kern)bneck_split_kernel<4, 1, 4> : (Kern)bneck_split_kernel<4, 1, 0>;
+        lds = BneckGeom<4, 1>::LDS + pad; threads = 256; wgs = we ? atoi(we) : 512;      // two persistent workgroups per CU
     } else {
-        ensure_max_dynamic_lds((const void*)bneck_split_kernel<8, 2>, BneckGeom<8, 2>::LDS);
-        const int wgs = we ? atoi(we) : 256;                        // one persistent workgroup per CU
-        hipLaunchKernelGGL((bneck_split_kernel<8, 2>), dim3(std::min(items, std::max(wgs, 8))), dim3(512), (BneckGeom<8, 2>::LDS), s, a);
+        fn = nch == 16 ? (Kern)bneck_split_kernel<8, 2, 16> : nch == 4 ? (Kern)bneck_split_kernel<8, 2, 4> : (Kern)bneck_split_kernel<8, 2, 0>;
+        lds = BneckGeom<8, 2>::LDS; threads = 512; wgs = we ? atoi(we) : 256;            // one persistent workgroup per CU
     }
+    ensure_max_dynamic_lds((const void*)fn, lds);
+    hipLaunchKernelGGL(fn, dim3(std::min(items, std::max(wgs, 8))), dim3(threads), lds, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -94,30 +95,11 @@ struct BneckGeom {
 
 // s_waitcnt immediate: vmcnt(n), expcnt and lgkmcnt untouched
 __host__ __device__ constexpr unsigned bn_vmcnt(int n) { return 0x0F70u | (unsigned)((n > 63 ? 63 : n) & 15) | ((unsigned)((n > 63 ? 63 : n) >> 4) << 14); }
-// Phase 1 with the DEEP ring (NCH = the compile-time number of 16-channel chunks, 16 or 4): the t1 / t2 / strip region is idle while conv1 streams x, so three more ring
-// slots live there (NR = 3) next to the ND dedicated ones: D = ND + NR chunks deep.  Chunk ch of an item lives in slot ch % D (slots below ND: dedicated).  Per wave and item
-// the request sequence is   S: fragments of chunks 0 .. ND - 1, 8 bias loads | barrier "region free" | E(ND) .. E(D - 1) | body(0) X(0) body(1) X(1) ...
-// with E(c) = the wave's npi x requests of chunk c followed by its 4 fragment loads, X(k) = E(k + D) if that chunk exists, else — when slot k % D is a dedicated one
-// and the workgroup has a next item — the npi x requests of the NEXT item's chunk k % D (its fragments are loaded at that item's start).  bn_p1_after = the number
-// of vector-memory operations the wave has issued behind the fragments of chunk ch when body(ch) starts: the vmcnt literal that says "chunk ch and its
-// fragments have landed" without waiting for anything younger (the counter is in-order).
-template <int D, int ND, int NCH>
-__host__ __device__ constexpr int bn_p1_after(int ch, int npi, bool has_next)
-{
-    int n = 0;
-    const int nd = ND < NCH ? ND : NCH;
-    if (ch < nd) {
-        n += (nd - 1 - ch) * 4 + 8;
-        for (int c = ND; c < D && c < NCH; ++c) n += npi + 4;
-        for (int k = 0; k < ch; ++k) n += k + D < NCH ? npi + 4 : ((k % D) < ND && has_next ? npi : 0);
-    } else if (ch < D) {
-        for (int c = ch + 1; c < D && c < NCH; ++c) n += npi + 4;
-        for (int k = 0; k < ch; ++k) n += k + D < NCH ? npi + 4 : ((k % D) < ND && has_next ? npi : 0);
-    } else {
-        for (int k = ch - D + 1; k < ch; ++k) n += k + D < NCH ? npi + 4 : ((k % D) < ND && has_next ? npi : 0);
-    }
-    return n;
-}
+// Phase 1, "B-direct" form (NCH = the compile-time number of 16-channel chunks, 16 or 4; round 6): conv1 is a 1 x 1 convolution, and a wave that owns whole pixel blocks
+// needs every x value exactly once — as the B fragment of its own MFMAs: lane (pixel, k-group) wants 16 bytes of hi and 16 bytes of lo, which lie NEXT to each other in
+// the tensor ([hi g][lo g] per 8 channels).  So the fragments are loaded straight from global memory into MFMA registers, DB chunks ahead, through plain buffer loads the
+// compiler counts itself: no LDS ring, no LDS-DMA pieces (whose issue cost — 100 - 185 cycles per 1-KiB piece per SIMD — is what bounded phase 1 of the ring forms at
+// ~30 B / clk / CU however deep the ring was: profiles/r06n_*), no fragment reads, no manual counter arithmetic.  The generic form (NCH = 0, any Cin) keeps the ring.
 template <class F, int... I>
 __device__ __forceinline__ void bn_for_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -125,8 +107,7 @@ template <int TH, int NSLOT, int NCH>
 __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
 {
     using G = BneckGeom<TH, NSLOT>;
-    constexpr int ND = NSLOT, NR = NCH > 0 ? 3 : 0, D = ND + NR;      // ring depth of phase 1 (NCH = 0: the generic form, dedicated slots only, any number of chunks)
-    static_assert(NR * G::XB <= G::REG, "the region slots fit the t1 region");
+    constexpr int DB = 4;                                  // B-direct form: chunks in flight per wave (registers: DB x (8 pixel-fragment + 16 weight-fragment))
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     constexpr unsigned OOB = 0x80000000u;
     constexpr int TW = BNK_TW, HW_ = BNK_HW, HPIX = G::HPIX, PS = BNK_PS, PBB = BNK_PBB, XB = G::XB, TPS = BNK_TPS, RH = TH / 2, N2 = G::N2;
@@ -196,39 +177,8 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         ++issued;
         if (++r_ch == nch1) { r_ch = 0; ++r_item; if (r_item < item_end) req_origin(r_item); }
     };
-    // ---- requests of one chunk with explicit geometry (deep ring: the order of requests is not the order of the chunks) ----
-    struct Geo { int iy0, ix0, gb; };
-    auto geo_of = [&](int item) -> Geo {
-        int n, ty, tx; decode(item, n, ty, tx);
-        Geo q_; q_.iy0 = ty * TH - 1; q_.ix0 = tx * TW - 1;
-        q_.gb = (((n * a.H + q_.iy0) * a.W + q_.ix0) * a.xcs + a.xoff) * 2;
-        return q_;
-    };
-    auto issue_chunk = [&](const Geo& ge, int c, char* dst) {
-        const unsigned so = (unsigned)(c * 64);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            if (k >= 3 && npb == 1) continue;              // (wave-uniform)
-            const int hy = hpk[k] & 0xFF, hx = (hpk[k] >> 8) & 0xFF, unit = (hpk[k] >> 16) & 7;
-            const int iy = ge.iy0 + hy, ix = ge.ix0 + hx;
-            const unsigned off = !(hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? OOB
-                                 : (unsigned)(ge.gb + ((hy * a.W + hx) * a.xcs + unit * 8) * 2);
-            if (hpk[k] != -2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, EAGLE_ABL_BNECK == 1 ? OOB : off, so, 0, 0);
-        }
-    };
-    char* const Rw = smem + pb0 * PBB;                     // this wave's part of a REGION slot (+ region slot * XB)
-    auto slot_of = [&](int ch) -> char* { const int sl = ch % (D > 0 ? D : 1); return sl < ND ? Xw + sl * XB : Rw + (sl - ND) * XB; };
-    // fragment ring of the deep form: AD[chunk % D][hi | lo][channel block]
-    u32x4 AD[NCH > 0 ? D : 1][2][2];
-    auto load_ad = [&](auto CH) {
-        constexpr int c = decltype(CH)::value;
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) AD[c % (D > 0 ? D : 1)][pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, (unsigned)(lane * 16 + (pt * 2 + m) * 1024), (unsigned)(c * 4096), 0);
-    };
-    Geo cur = geo_of(item0);
+    // fragment rings of the B-direct form: AD[chunk % DB][hi | lo][channel block], BX[chunk % DB][pixel block][hi | lo]
+    u32x4 AD[NCH > 0 ? DB : 1][2][2], BX[NCH > 0 ? DB : 1][1][2];
     // weight image 1: [chunk][hi | lo][2 blocks][lane][8]: 4 KiB per chunk.  A1[parity of the chunk inside its item][hi | lo][channel block]: the fragments of a chunk are
     // requested right BEHIND that chunk's x requests, NSLOT chunks ahead of their use, into registers with static names (no rotation copies: hipcc waits at a copy, not
     // at the use, and — the counter being in-order — with it for every older request)
@@ -248,11 +198,6 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    if constexpr (NCH > 0) {
-#pragma unroll
-        for (int c = 0; c < ND && c < NCH; ++c) issue_chunk(cur, c, slot_of(c));
-        __builtin_amdgcn_sched_barrier(0);
-    }
     const unsigned w1lane = (unsigned)(mbw * 1024 + lane * 16);
 #if EAGLE_BNECK_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
@@ -268,8 +213,6 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
             // (the fragments of the item's first two chunks are requested here, not across the item boundary: 32 registers that would otherwise live through phases 2 / 3)
             load_a1(P0, 0);
             load_a1(P1c, nch1 > 1 ? 1 : 0);
-        } else {
-            bn_for_seq(std::make_integer_sequence<int, (ND < NCH ? ND : NCH)>{}, [&](auto I_) { load_ad(I_); });
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -278,53 +221,55 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                 const float4 bv = *(const float4*)(a.b1 + m * 32 + jj * 8 + kh * 4);
                 acc1[0][m][jj * 4 + 0] = bv.x; acc1[0][m][jj * 4 + 1] = bv.y; acc1[0][m][jj * 4 + 2] = bv.z; acc1[0][m][jj * 4 + 3] = bv.w;
             }
-            if constexpr (NCH == 0) acc1[1][m] = acc1[0][m];      // (deep form: copied inside body 0, behind its wait)
+            if constexpr (NCH == 0) acc1[1][m] = acc1[0][m];      // (B-direct form: copied inside body 0)
         }
         if constexpr (NCH > 0) {
-            // =========== deep ring: D = ND + 3 chunks, the three extra slots in the idle t1 region ===========
-            const bool has_next = item + 1 < item_end;
-            const Geo nxt = has_next ? geo_of(item + 1) : cur;
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();                    // "region free": every wave has left phase 3 of the previous item (its strip reads fed stores that have issued)
-            __builtin_amdgcn_sched_barrier(0);
-            bn_for_seq(std::make_integer_sequence<int, (D < NCH ? D : NCH) - (ND < NCH ? ND : NCH)>{}, [&](auto I_) {
-                constexpr int c = decltype(I_)::value + ND;
-                issue_chunk(cur, c, slot_of(c));
-                __builtin_amdgcn_sched_barrier(0);
-                load_ad(std::integral_constant<int, c>{});
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            bn_for_seq(std::make_integer_sequence<int, NCH>{}, [&](auto CH) {
-                constexpr int ch = decltype(CH)::value;
-                if (npb == 2) { if (has_next) __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 5, true))); else __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 5, false))); }
-                else { if (has_next) __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 3, true))); else __builtin_amdgcn_s_waitcnt(bn_vmcnt(bn_p1_after<D, ND, NCH>(ch, 3, false))); }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ch == 0) { acc1[1][0] = acc1[0][0]; acc1[1][1] = acc1[0][1]; }      // (the bias loads are older than everything the wait above lets through)
-                const char* hb = slot_of(ch) + lx * PS + kh * 16;
+            // =========== B-direct: the pixel fragments of conv1 straight from global memory into MFMA registers ===========
+            unsigned xo[2];
+            {
+                const int gb = (((n * a.H + oy0 - 1) * a.W + ox0 - 1) * a.xcs + a.xoff) * 2;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (j == 0 || npb == 2) {
-                        const half8 Bh = *(const half8*)(hb + j * PBB), Bl = *(const half8*)(hb + j * PBB + 32);
+                    const int p = (pb0 + j) * 32 + lx;
+                    const int hy = (int)(((unsigned)p * 1928u) >> 16), hx = p - hy * HW_;      // p / 34 for p < 2^11
+                    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+                    const bool live = j < npb && p < HPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    xo[j] = live ? (unsigned)(gb + (hy * a.W + hx) * a.xcs * 2 + kh * 32) : OOB;
+                }
+            }
+            // PIXEL-BLOCK-major order: all NCH chunks of the wave's first pixel block, then of its second one.  A pixel's record is 1 KiB of contiguous memory (256 channels x 4
+            // bytes): walked chunk after chunk by the same two lanes, DB chunks in flight, it is ONE DRAM page visited once; in chunk-major order every page was visited NCH
+            // times, microseconds apart, for 64 bytes each (3.4 TB/s of x at L2 level however deep the prefetch was: profiles/r06o_*).  The weight fragments are streamed once
+            // per pixel block (L1 hits).
+            auto load_e = [&](auto J, auto CH) {              // E(j, c): the x fragments of chunk c of pixel block j (hi at +0, lo at +16 of the lane's 32 bytes), then the weight fragments
+                constexpr int c = decltype(CH)::value, j = decltype(J)::value;
+                BX[c % DB][0][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, EAGLE_ABL_BNECK == 1 ? OOB : xo[j], c * 64, 0);
+                BX[c % DB][0][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, EAGLE_ABL_BNECK == 1 ? OOB : xo[j] + 16u, c * 64, 0);
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            acc1[j][m] = BN_MFMA((half8)AD[ch % D][0][m], Bh, acc1[j][m]);
-                            acc1[j][m] = BN_MFMA((half8)AD[ch % D][0][m], Bl, acc1[j][m]);
-                            acc1[j][m] = BN_MFMA((half8)AD[ch % D][1][m], Bh, acc1[j][m]);
-                        }
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) AD[c % DB][pt][m] = __builtin_amdgcn_raw_buffer_load_b128(w1rs, (unsigned)(lane * 16 + (pt * 2 + m) * 1024), (unsigned)(c * 4096), 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto run_pb = [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                bn_for_seq(std::make_integer_sequence<int, (DB < NCH ? DB : NCH)>{}, [&](auto CH) { load_e(J, CH); });
+                bn_for_seq(std::make_integer_sequence<int, NCH>{}, [&](auto CH) {
+                    constexpr int ch = decltype(CH)::value;
+                    if constexpr (ch == 0 && j == 0) { acc1[1][0] = acc1[0][0]; acc1[1][1] = acc1[0][1]; }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        acc1[j][m] = BN_MFMA((half8)AD[ch % DB][0][m], (half8)BX[ch % DB][0][0], acc1[j][m]);
+                        acc1[j][m] = BN_MFMA((half8)AD[ch % DB][0][m], (half8)BX[ch % DB][0][1], acc1[j][m]);
+                        acc1[j][m] = BN_MFMA((half8)AD[ch % DB][1][m], (half8)BX[ch % DB][0][0], acc1[j][m]);
                     }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's fragment reads of the slot are complete
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ch + D < NCH) {
-                    issue_chunk(cur, ch + D, slot_of(ch));
                     __builtin_amdgcn_sched_barrier(0);
-                    load_ad(std::integral_constant<int, ch + D>{});
-                } else if constexpr ((ch % D) < ND) {
-                    if (has_next) issue_chunk(nxt, ch % D, slot_of(ch));      // the next item's chunk ch % D: the dedicated slot has seen its last chunk of this item
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            cur = nxt;
+                    if constexpr (ch + DB < NCH) load_e(J, std::integral_constant<int, ch + DB>{});
+                });
+            };
+            __builtin_amdgcn_sched_barrier(0);               // (the bias loads above are older than every fragment request)
+            run_pb(std::integral_constant<int, 0>{});
+            if (npb == 2) run_pb(std::integral_constant<int, 1>{});
         } else {
         auto p1_body = [&](auto PAR, int ch) {
             // chunk g and its weight fragments have landed: everything older than the requests of chunk g + 1 (3 or 5 x requests + 4 fragment loads per wave) is
@@ -660,19 +605,21 @@ void bneck_launch(const BneckLaunch& L, hipStream_t s)
         fail(EAGLE_E_INVALID, "fused bottleneck: a tensor of %d frames reaches 2 GiB (32-bit tensor offsets); use a smaller device batch", a.N);
     const char* we = getenv("EAGLE_BNECK_WGS");                     // (read per launch: the parity tests make several items share a workgroup)
     const int items = a.tiles_x * a.tiles_y * a.N;
-    // ring: 1 (default) = the deep phase-1 ring where the kernel has a compile-time chunk count (Cin = 256: 16 chunks, Cin = 64: 4); 0 = the generic form for every Cin
-    const char* re = getenv("EAGLE_BNECK_RING");
-    const int nch = (re && atoi(re) == 0) ? 0 : (a.nch1 == 16 ? 16 : a.nch1 == 4 ? 4 : 0);
+    // phase 1: "ring" (default) = x through the wave-private LDS-DMA ring, any Cin; EAGLE_BNECK_P1=direct = the B-direct form (pixel fragments straight from global memory
+    // into MFMA registers, pixel-block-major; compile-time chunk counts: Cin = 256 and 64).  Measured on MI355X, B = 50, Cin = 256 (profiles/r06o_*, r06p_*): ring 1341 us,
+    // direct 1380 (chunk-major) / 1411 (pixel-block-major) — phase 1 takes ~22 us per tile (x at ~4 TB/s at L2 level) in every form, ring two or five chunks deep included
+    const char* re = getenv("EAGLE_BNECK_P1");
+    const int nch = (re && !strcmp(re, "direct")) ? (a.nch1 == 16 ? 16 : a.nch1 == 4 ? 4 : 0) : 0;
     typedef void (*Kern)(BneckArgs);
     const char* pe = getenv("EAGLE_BNECK_LDS_PAD");                 // developer: extra LDS bytes per workgroup (forces ONE workgroup per CU in form 1)
     const int pad = pe ? atoi(pe) : 0;
     Kern fn; int lds, threads, wgs;
     if (form == 1) {
         fn = nch == 16 ? (Kern)bneck_split_kernel<4, 1, 16> : nch == 4 ? (Kern)bneck_split_kernel<4, 1, 4> : (Kern)bneck_split_kernel<4, 1, 0>;
-        lds = BneckGeom<4, 1>::LDS + pad; threads = 256; wgs = we ? atoi(we) : 512;      // two persistent workgroups per CU
+        lds = (nch ? BneckGeom<4, 1>::REG : BneckGeom<4, 1>::LDS) + pad; threads = 256; wgs = we ? atoi(we) : 512;      // two persistent workgroups per CU (the B-direct form has no x ring in LDS)
     } else {
         fn = nch == 16 ? (Kern)bneck_split_kernel<8, 2, 16> : nch == 4 ? (Kern)bneck_split_kernel<8, 2, 4> : (Kern)bneck_split_kernel<8, 2, 0>;
-        lds = BneckGeom<8, 2>::LDS; threads = 512; wgs = we ? atoi(we) : 256;            // one persistent workgroup per CU
+        lds = nch ? BneckGeom<8, 2>::REG : BneckGeom<8, 2>::LDS; threads = 512; wgs = we ? atoi(we) : 256;            // one persistent workgroup per CU
     }
     ensure_max_dynamic_lds((const void*)fn, lds);
     hipLaunchKernelGGL(fn, dim3(std::min(items, std::max(wgs, 8))), dim3(threads), lds, s, a);

@@ -31,16 +31,20 @@ def _oracle(x, ws, res):
 SHAPES = [(1, 8, 32), (2, 19, 45), (3, 1, 1), (1, 7, 65), (5, 17, 30), (1, 9, 33), (2, 16, 64)]
 
 
+@pytest.mark.parametrize("p1", ["ring", "direct"])
 @pytest.mark.parametrize("form", ["0", "1"])
 @pytest.mark.parametrize("wgs", ["256", "8"])
 @pytest.mark.parametrize("cin", [256, 64, 16])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_fused_bottleneck_against_the_oracle(shape, cin, wgs, form, monkeypatch):
+def test_fused_bottleneck_against_the_oracle(shape, cin, wgs, form, p1, monkeypatch):
     """Ragged maps, partial tiles in both directions, a 1 x 1 map, several tiles per workgroup (EAGLE_BNECK_WGS=8: the x ring runs on across items and the
     next tile's first chunks are requested under phases 2 / 3), the identity shortcut (Cin = 256) and a separate residual tensor (block 0: Cin = 64)."""
     from eagle_amd import lib
     monkeypatch.setenv("EAGLE_BNECK_WGS", wgs)
     monkeypatch.setenv("EAGLE_BNECK_FORM", form)        # 0: tile 8 x 32, one 8-wave workgroup per CU; 1: tile 4 x 32, two 4-wave workgroups per CU, one-slot x ring
+    monkeypatch.setenv("EAGLE_BNECK_P1", p1)            # phase 1: x through the LDS-DMA ring (default) / pixel fragments straight from global memory (Cin = 256, 64)
+    if p1 == "direct" and cin == 16:
+        pytest.skip("the B-direct form exists for Cin = 256 and 64; any other Cin takes the ring")
     n, h, w = shape
     x = _rand((n, h, w, cin), 71)
     ws = _weights(cin, 72)
@@ -99,7 +103,8 @@ def test_fused_bottleneck_forms_agree_with_co_resident_workgroups(monkeypatch):
     y0 = lib.op_bottleneck(x, *ws)
     assert np.isfinite(y0).all()
     monkeypatch.setenv("EAGLE_BNECK_FORM", "1")
-    for wgs in ("512", "1024", "512"):
+    for wgs, p1 in (("512", "ring"), ("1024", "ring"), ("512", "direct"), ("512", "ring")):
         monkeypatch.setenv("EAGLE_BNECK_WGS", wgs)
+        monkeypatch.setenv("EAGLE_BNECK_P1", p1)
         y1 = lib.op_bottleneck(x, *ws)
-        assert np.array_equal(y0, y1), f"form 1 ({wgs} workgroups) differs from form 0 in {int((y0 != y1).sum())} values"
+        assert np.array_equal(y0, y1), f"form 1 ({wgs} workgroups, phase 1 {p1}) differs from form 0 in {int((y0 != y1).sum())} values"

@@ -23,7 +23,7 @@ tf = tw = n = 0
 for k in fetch:
     # the convolution family of the KEY-POINT network's precision (the default handle runs its detector in the exact fp32 family: those
     # conv_f32_kernel launches belong to `detector_convs`, not to the roofline family)
-    fam = ("conv_f32_kernel",) if out["precision"] == "f32" else ("conv_f16", "conv_split")
+    fam = ("conv_f32_kernel",) if out["precision"] == "f32" else ("conv_f16", "conv_split", "bneck_split")      # (bneck_split_kernel: a whole Bottleneck of layer 1 as one launch, round 6)
     if not any(t in k for t in fam):
         continue
     c, v = fetch[k]

@@ -80,7 +80,10 @@ __device__ __forceinline__ void bn_split4(float v0, float v1, float v2, float v3
 // Tile forms.  <TH = 8, NSLOT = 2>: 8 waves, ONE workgroup per CU (155 KB of LDS), two-deep x ring.  <TH = 4, NSLOT = 1>: 4 waves, tile 4 x 32, 72 KB of LDS — TWO workgroups
 // per CU, whose phases interleave on the CU (one streams x or stores while the other issues MFMAs); the x ring has ONE slot per wave (the next chunk is requested when the
 // wave has read the current one; the CU's other workgroup covers the latency), conv1 is recomputed on 1.59x instead of 1.33x the pixels.
-constexpr int BNK_TW = 32, BNK_HW = BNK_TW + 2, BNK_PS = 80, BNK_PBB = 32 * BNK_PS, BNK_TPS = 272, BNK_STRIP = 4096;
+// x ring records: 64 bytes per pixel and 16-channel chunk, NO padding: [hi g0][hi g1][lo g0][lo g1] with the 16-byte unit XOR-swizzled by the pixel (unit ^ ((pixel >> 2) & 3)):
+// the 16 pixels of a ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}) fall on 16 distinct 16-byte columns — conflict-free like the 80-byte padded record of
+// the first forms, with 22 instead of 28 LDS-DMA pieces per chunk and CU (their issue cost is what phase 1 pays: profiles/r06n_*) and whole pieces per pixel block
+constexpr int BNK_TW = 32, BNK_HW = BNK_TW + 2, BNK_PS = 64, BNK_PBB = 32 * BNK_PS, BNK_TPS = 272, BNK_STRIP = 4096;
 template <int TH, int NSLOT>
 struct BneckGeom {
     static constexpr int NW = TH;                                        // waves per workgroup: wave (q = w >> 1, mb = w & 1) owns rows q and q + TH / 2 in phases 2 / 3
@@ -144,16 +147,17 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         ty = t % a.tiles_y; t /= a.tiles_y;
         tx = t % a.tiles_x; n = t / a.tiles_x;
     };
-    // ---- x ring: request k of this wave fills the 1-KiB slab k of its region (16-byte slot e = k * 64 + lane: local pixel e / 5, record slot e % 5; slot 4 = padding) ----
-    int hpk[5];
+    // ---- x ring: request k of this wave fills the 1-KiB piece k of its region (16-byte slot e = k * 64 + lane: local pixel e / 4, physical unit e % 4 = record slot ^ swizzle) ----
+    int hpk[4];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const int e = k * 64 + lane;
-        const int lp = e / 5, slot = e - lp * 5, pix = pb0 * 32 + lp;
+        const int lp = e >> 2, slot = (e & 3) ^ ((lp >> 2) & 3), pix = pb0 * 32 + lp;
         const int hy = pix / HW_, hx = pix - hy * HW_;
-        // record slot (hi g0, hi g1, lo g0, lo g1) <- the tensor's 16-byte unit (hi g0, lo g0, hi g1, lo g1); -2: the lane lies beyond the wave's region (no request at all)
-        hpk[k] = lp >= 32 * npb ? -2 : (pix < HPIX && slot < 4) ? (hy | (hx << 8) | (((slot & 1) * 2 + (slot >> 1)) << 16)) : -1;
+        // record slot (hi g0, hi g1, lo g0, lo g1) <- the tensor's 16-byte unit (hi g0, lo g0, hi g1, lo g1); -1: a pixel beyond the halo (zeros)
+        hpk[k] = pix < HPIX ? (hy | (hx << 8) | (((slot & 1) * 2 + (slot >> 1)) << 16)) : -1;
     }
+    const int bsw = (lx >> 2) & 3, bhi = lx * PS + ((kh ^ bsw) * 16), blo = lx * PS + (((2 + kh) ^ bsw) * 16);      // the lane's hi / lo fragment inside a pixel block of a slot
     int issued = 0, g = 0;                                 // chunks requested / chunk being consumed (global over the workgroup's items); per wave
     int r_item = item0, r_ch = 0, r_iy0 = 0, r_ix0 = 0, r_gb = 0;
     auto req_origin = [&](int item) {
@@ -165,14 +169,13 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         char* const dst = Xw + (issued % NSLOT) * XB;
         const unsigned so = (unsigned)(r_ch * 64);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            if (k >= 3 && npb == 1) continue;              // (wave-uniform)
+        for (int k = 0; k < 4; ++k) {
+            if (k >= 2 && npb == 1) continue;              // (wave-uniform: a wave with one pixel block requests two pieces)
             const int hy = hpk[k] & 0xFF, hx = (hpk[k] >> 8) & 0xFF, unit = (hpk[k] >> 16) & 7;
             const int iy = r_iy0 + hy, ix = r_ix0 + hx;
             const unsigned off = !(hpk[k] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? OOB
                                  : (unsigned)(r_gb + ((hy * a.W + hx) * a.xcs + unit * 8) * 2);
-            if (hpk[k] != -2)                               // (lanes beyond the region are masked off: LDS-DMA writes nothing for inactive lanes)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, (EAGLE_ABL_BNECK == 1 && issued >= NSLOT) ? OOB : off, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, (EAGLE_ABL_BNECK == 1 && issued >= NSLOT) ? OOB : off, so, 0, 0);
         }
         ++issued;
         if (++r_ch == nch1) { r_ch = 0; ++r_item; if (r_item < item_end) req_origin(r_item); }
@@ -272,19 +275,19 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
             if (npb == 2) run_pb(std::integral_constant<int, 1>{});
         } else {
         auto p1_body = [&](auto PAR, int ch) {
-            // chunk g and its weight fragments have landed: everything older than the requests of chunk g + 1 (3 or 5 x requests + 4 fragment loads per wave) is
+            // chunk g and its weight fragments have landed: everything older than the requests of chunk g + 1 (2 or 4 x requests + 4 fragment loads per wave) is
             // complete.  The first chunk of an item waits for everything (output stores of the previous item may still be in flight: stores and loads share the counter)
             // (the request behind the item's LAST chunk carries no fragment loads: the next item loads its own)
             if (NSLOT == 1 || ch == 0 || issued != g + 2) __builtin_amdgcn_s_waitcnt(0x0F70);
-            else if (ch + 1 >= nch1) { if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F75); else __builtin_amdgcn_s_waitcnt(0x0F73); }
-            else if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F79);
-            else __builtin_amdgcn_s_waitcnt(0x0F77);
+            else if (ch + 1 >= nch1) { if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F72); }
+            else if (npb == 2) __builtin_amdgcn_s_waitcnt(0x0F78);
+            else __builtin_amdgcn_s_waitcnt(0x0F76);
             __builtin_amdgcn_sched_barrier(0);
-            const char* hb = Xw + (g % NSLOT) * XB + lx * PS + kh * 16;
+            const char* hb = Xw + (g % NSLOT) * XB;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j == 0 || npb == 2) {
-                    const half8 Bh = *(const half8*)(hb + j * PBB), Bl = *(const half8*)(hb + j * PBB + 32);
+                    const half8 Bh = *(const half8*)(hb + j * PBB + bhi), Bl = *(const half8*)(hb + j * PBB + blo);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         acc1[j][m] = BN_MFMA((half8)A1[PAR][0][m], Bh, acc1[j][m]);

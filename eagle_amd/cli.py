@@ -57,6 +57,9 @@ def main(argv=None):
     ap.add_argument("--num-homography", type=int, default=1, help="homography solves per second (main.py:27: 1)")
     ap.add_argument("--num-keypoint-detection", type=int, default=3, help="key-point model runs per second (main.py:27: 3)")
     ap.add_argument("--every-frame", action="store_true", help="key-points and homography on every frame (stateless configuration)")
+    ap.add_argument("--letterbox", default="rect", choices=["rect", "square"],
+                    help="detector input geometry: 'rect' = ultralytics LetterBox(auto=True), what the reference's .pt detectors run with (cm.py:56-57); 'square' = auto=False, the "
+                         "static imgsz x imgsz input of its exported ONNX detector (the CPU default, cm.py:54-55)")
     ap.add_argument("--calibration", action="store_true")
     ap.add_argument("--tracker", action="store_true", help="key players by track id (BoT-SORT association) instead of the detection index")
     ap.add_argument("--reid", action="store_true", help="with --tracker: appearance matching with OSNet-x0.25 embeddings, as the reference configures BotSort (cm.py:66-72)")
@@ -87,7 +90,7 @@ def main(argv=None):
                          "or --synthetic-weights to run seeded random networks on purpose")
     if hs is None or ys is None:
         print("WARNING: running with seeded RANDOM network weights: the output has the reference's schema but no meaning", flush=True)
-    model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, batch=min(a.batch, max(n, 1)),
+    model = CoordinateModel(frame_hw=(h, w), detector=a.detector, det_imgsz=a.imgsz, letterbox=a.letterbox, batch=min(a.batch, max(n, 1)),
                             precision=a.precision, detector_precision=a.detector_precision, allow_saturation=a.allow_saturation, device=a.device, seed=a.seed,
                             hrnet_state_dict=hs, detector_state_dict=ys, tracker=a.tracker, camera_motion=a.camera_motion or False,
                             reid=a.reid, reid_state_dict=({("reid." + k): v for k, v in load_state_dict(a.reid_weights).items()} if a.reid_weights else None))

@@ -149,7 +149,7 @@ def load():
 EXPORTS = ["eagle_abi_sizes", "eagle_default_config", "eagle_create", "eagle_destroy", "eagle_last_error", "eagle_get_config", "eagle_resolve_config", "eagle_load_weights",
            "eagle_finalize_weights", "eagle_process_frames", "eagle_process_device_frames", "eagle_device_alloc",
            "eagle_device_free", "eagle_device_upload", "eagle_host_alloc", "eagle_host_free", "eagle_reproject", "eagle_comm_id", "eagle_comm_init", "eagle_gather",
-           "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_fuse_sum", "eagle_op_preprocess",
+           "eagle_set_profiling", "eagle_get_timings", "eagle_get_kernel_times", "eagle_op_conv2d", "eagle_op_bottleneck", "eagle_op_fuse_sum", "eagle_op_preprocess", "eagle_op_preprocess_lb",
            "eagle_op_find_homography", "eagle_clip_open", "eagle_clip_close", "eagle_clip_detect_objects", "eagle_clip_detect_keypoints", "eagle_clip_get_keypoints",
            "eagle_clip_set_keypoints", "eagle_clip_flow", "eagle_clip_run", "eagle_clip_fetch", "eagle_debug", "eagle_track_open", "eagle_track_frames", "eagle_track_frames_cmc", "eagle_clip_motion_ecc", "eagle_clip_motion", "eagle_team_colors",
            "eagle_reid_features", "eagle_track_frames_reid"]

@@ -216,6 +216,7 @@ struct EagleHandle {
         int capture_backoff = 0, capture_skip = 0;       // steps to run eagerly before the next capture attempt after one that could not get its turn
     } sb[2];
     bool graph_broken = false;                           // a capture failed half-way: this handle runs plain launches from now on
+    int graph_captures = 0, graph_skipped = 0;           // EagleTimings::graph_captures / graph_skipped
     std::unique_ptr<Net> hr, yo, misc, reid;
     // K16 appearance embeddings (OSNet-x0.25; built when the "reid.*" tensors were loaded): REID_NB crops per pass
     TView reid_in; float* reid_feats = nullptr; EagleCrop* reid_crops = nullptr; EagleCrop* reid_crops_h = nullptr; float* reid_feats_h = nullptr;
@@ -954,9 +955,11 @@ static void launch_step(EagleHandle* h, int p, const uint8_t* d_src, int n_activ
                 if (sb.graphs.size() >= 16) { (void)hipGraphExecDestroy(sb.graphs.begin()->second); sb.graphs.erase(sb.graphs.begin()); }      // (frame counts 1 .. batch: bounded)
                 it = sb.graphs.emplace(n_active, ge).first;
                 sb.capture_backoff = 0;
+                ++h->graph_captures;
             } else {
                 sb.capture_backoff = std::min(64, std::max(1, sb.capture_backoff * 2));
                 sb.capture_skip = sb.capture_backoff;
+                ++h->graph_skipped;
             }
         }
         if (it != sb.graphs.end()) { HIP_CHECK(hipGraphLaunch(it->second, h->s_main)); replayed = true; }
@@ -1909,6 +1912,7 @@ int eagle_get_timings(EagleHandle* h, EagleTimings* t)
 {
     if (!h || !t) return EAGLE_E_INVALID;
     *t = h->timings;
+    t->graph_captures = h->graph_captures; t->graph_skipped = h->graph_skipped;
     return EAGLE_OK;
 }
 

@@ -41,7 +41,7 @@ class EagleConfig(C.Structure):
 class EagleTimings(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("conv_ms", C.c_float), ("n_launches", C.c_int32),
                 ("n_conv_launches", C.c_int32), ("conv_flop", C.c_double), ("sat_events", C.c_int32), ("sat_frames", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("graph_captures", C.c_int32), ("graph_skipped", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class EagleTrackParams(C.Structure):

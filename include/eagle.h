@@ -264,7 +264,10 @@ typedef struct EagleTimings {
     double conv_flop;          /* algorithmic FLOP of the convolutions of the last call (2*MAC) */
     int32_t sat_events;        /* EAGLE_PREC_F32S: lane-level activation stores of the last eagle_process_* / eagle_clip_fetch call that were clipped at +-4094 */
     int32_t sat_frames;        /* ... and the number of frames they occurred in (0 / 0 in every healthy run) */
-    int32_t reserved[6];
+    int32_t graph_captures;    /* hipGraph captures this handle has made since eagle_create (cumulative: one per pipeline slot and frame count, ~80 ms each; a caller that
+                                  sees this number grow call after call is paying for re-captures) */
+    int32_t graph_skipped;     /* ... and capture attempts given up because another call of the process held the capture lock (the step then ran as plain launches) */
+    int32_t reserved[4];
 } EagleTimings;
 int eagle_set_profiling(EagleHandle* h, int per_kernel_events);
 int eagle_get_timings(EagleHandle* h, EagleTimings* t);

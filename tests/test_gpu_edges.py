@@ -432,6 +432,87 @@ def test_three_handles_on_three_threads_capture_their_graphs_concurrently(state_
         assert records_equal(out[k][0], ref) and records_equal(out[k][1], ref[k:k + 2]), k
 
 
+def test_graph_instances_are_cached_per_frame_count_and_survive_a_moving_source(state_dicts):
+    """round 5 kept ONE graph per pipeline slot, keyed on (source pointer, frame count) — a call whose last step is ragged re-captured twice per
+    call (~80 ms each, process-exclusive), and a caller walking a resident clip re-captured on every call.  Now: one instance per (slot, frame count), device-fed
+    calls staged into the slot's own buffer.  EagleTimings::graph_captures is cumulative per handle: the second identical call, a call with the same step shapes at
+    another source address and a host-fed call must not add a capture; records stay equal to a handle that replays nothing."""
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    frames = np.stack([synth.frame(1, t) for t in range(7)])
+    plain = CoordinateModel(precision="f16", batch=3, hrnet_state_dict=hs, detector_state_dict=ys, use_graph=0)
+    ref = plain.process_records(frames)
+    plain.handle.close()
+    m = CoordinateModel(precision="f16", batch=3, hrnet_state_dict=hs, detector_state_dict=ys, use_graph=1)
+    h = m.handle
+    a = m.process_records(frames)                            # 3 + 3 + 1 frames: slot 0 sees 3 and 1, slot 1 sees 3 -> three instances
+    c0 = h.timings().graph_captures
+    assert c0 == 3, c0
+    b = m.process_records(frames)
+    assert h.timings().graph_captures == c0, "an identical second call re-captured"
+    d = h.upload(np.concatenate([frames, frames]))           # a resident clip walked at two offsets: another source pointer per call
+    out1 = np.zeros(7, a.dtype); out2 = np.zeros(7, a.dtype)
+    h.process_device(d, 7, out1)
+    fsz = frames[0].nbytes
+    import ctypes
+    h.process_device(ctypes.c_void_p(d.value + 7 * fsz), 7, out2)
+    h.free(d)
+    assert h.timings().graph_captures == c0, "a device-fed call at another address re-captured"
+    assert h.timings().graph_skipped == 0
+    h.close()
+    for got in (a, b, out1, out2):
+        assert records_equal(got, ref)
+
+
+def test_a_capture_never_waits_for_a_long_call_of_another_handle(state_dicts):
+    """a capture needs the process-wide lock exclusively; round 5 waited for it without a bound, i.e. for every in-flight call of every handle (a
+    multi-second clip call; a collective blocked on this very thread).  Now it tries for 10 ms and otherwise runs the step as plain launches.  Thread A keeps a handle
+    busy with long calls; thread B creates a handle that wants to capture and must finish its short calls promptly, with records equal to the reference."""
+    import threading
+    import time
+    from eagle_amd import synth
+    from eagle_amd.coordinate_model import CoordinateModel
+    hs, ys = state_dicts
+    long_clip = np.stack([synth.frame(2, t % 5) for t in range(200)])
+    short = np.stack([synth.frame(1, t) for t in range(2)])
+    ref_m = CoordinateModel(precision="f16", batch=2, hrnet_state_dict=hs, detector_state_dict=ys, use_graph=0)
+    ref = ref_m.process_records(short)
+    ref_m.handle.close()
+    busy = CoordinateModel(precision="f16", batch=25, hrnet_state_dict=hs, detector_state_dict=ys, use_graph=0)
+    busy.process_records(long_clip[:25])                     # warm
+    stop, err, spans = threading.Event(), [], []
+
+    def hog():
+        try:
+            while not stop.is_set():
+                busy.process_records(long_clip)              # ~0.1 - 0.2 s per call on the fp16 family, back to back
+        except Exception as e:                               # pragma: no cover
+            err.append(repr(e))
+
+    t = threading.Thread(target=hog)
+    t.start()
+    try:
+        time.sleep(0.05)
+        m = CoordinateModel(precision="f16", batch=2, hrnet_state_dict=hs, detector_state_dict=ys, use_graph=1)
+        for _ in range(12):
+            t0 = time.perf_counter()
+            got = m.process_records(short)
+            spans.append(time.perf_counter() - t0)
+            assert records_equal(got, ref)
+        tm = m.handle.timings()
+        m.handle.close()
+    finally:
+        stop.set()
+        t.join(timeout=120)
+    busy.handle.close()
+    assert not err and not t.is_alive(), err
+    # every call returned: nothing waited for the other handle's stream of long calls without a bound (a capture either got its turn between two of them or was skipped)
+    assert max(spans) < 5.0, spans
+    assert tm.graph_captures + tm.graph_skipped >= 1, (tm.graph_captures, tm.graph_skipped)
+    print("captures", tm.graph_captures, "skipped", tm.graph_skipped, "slowest call %.3f s" % max(spans))
+
+
 def test_geometry_bit_identical_while_another_handle_runs_the_fp16_networks():
     """VERDICT r2 task 9: the concurrent-handle check of the LK kernel, extended to the geometry kernel (`post_kernel`: threshold / dedup / line
     synthesis / RANSAC / DLT / LM / projection, all fp64 and bit-identical to the oracle when run alone).  `eagle_op_find_homography` — the same

@@ -27,6 +27,8 @@ def wrap_file(path, width=160):
         if fence or not s or s.startswith("|") or line.startswith("#") or s.startswith("<") or re.match(r"^\s*[-=]{3,}\s*$", line):
             flush(); out.append(line); continue
         m = MARK.match(line)
+        if block is not None and not m and s.startswith("**") and block[1] == "":      # a bold lead-in opens a new paragraph
+            flush(); out.append("")
         if m:
             flush(); block = [m.group(1), m.group(2), line[m.end():].strip()]
         elif block is not None:

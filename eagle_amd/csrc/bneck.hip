@@ -106,7 +106,11 @@ __host__ __device__ constexpr unsigned bn_vmcnt(int n) { return 0x0F70u | (unsig
 template <class F, int... I>
 __device__ __forceinline__ void bn_for_seq(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
-template <int TH, int NSLOT, int NCH>
+// DSF (block 0 of layer 1, Cin = 64): the 1 x 1 downsample branch of the shortcut (kh.py:328: conv 64 -> 256 + BatchNorm on x) is computed INSIDE phase 3 instead of being read
+// as a 256-channel residual tensor that another launch wrote: conv3 becomes a K = 128 product over [t2 | x] — the weight image holds W3's four chunks followed by the downsample
+// weights' four, both on ONE power-of-two scale, the bias is b3 + bd — and x's inner pixels arrive as B-direct fragments (16 loads per wave and tile, held in the registers the
+// residual pieces would have used).  Saves the downsample launch (x read, 1.66 GB written) and the residual read (1.66 GB) of the block.
+template <int TH, int NSLOT, int NCH, bool DSF = false>
 __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
 {
     using G = BneckGeom<TH, NSLOT>;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         // phase 3 works in four passes (pass p: output channels 64 p + 32 mbw .. + 31 of this wave's two rows); the weight fragments and the residual pieces of a pass
         // are requested one pass ahead into the other half of a double buffer — those of pass 0 here, so that they travel under phase 2.
         // weight image 3: [chunk][hi | lo][8 blocks][lane][8]
-        u32x4 A3[4][2], rres[2][2][4];
+        u32x4 A3[4][2], rres[DSF ? 1 : 2][DSF ? 1 : 2][DSF ? 1 : 4], XD[DSF ? 4 : 1][2][2];      // XD[chunk of x][row][hi | lo]: the inner pixels' x fragments (DSF)
         f32x16 acc3[2];                                     // block 0 is also where the pass' bias / descale lands (requested as soon as the previous pass has read it for the last time)
         auto p3_bias = [&](int pass) {
 #pragma unroll
@@ -349,10 +353,26 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                     A3[c][pt] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (unsigned)(((c * 2 + pt) * 8 + pass * 2 + mbw) * 1024 + lane * 16), 0, 0);
         };
         auto p3_residual = [&](int buf, int pass) {
+            if constexpr (!DSF) {
 #pragma unroll
-            for (int ri = 0; ri < 2; ++ri)
+                for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rres[buf][ri][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_r[ri][i], (pass * 2 + mbw) * 128, 0);
+                    for (int i = 0; i < 4; ++i) rres[buf][ri][i] = __builtin_amdgcn_raw_buffer_load_b128(rrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_r[ri][i], (pass * 2 + mbw) * 128, 0);
+            }
+        };
+        auto p3_xd = [&]() {                                // DSF: lane (pixel lx, k-group kh) of row ri: 16 bytes of hi and 16 of lo per 16-channel chunk of x, straight into B-fragment registers
+            if constexpr (DSF) {
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri) {
+                    const int oy = oy0 + q + RH * ri, ox = ox0 + lx;
+                    const unsigned xo = (oy < a.H && ox < a.W) ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.xcs + a.xoff) * 2 + kh * 32) : OOB;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        XD[c][ri][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, c * 64, 0);
+                        XD[c][ri][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo + 16u, c * 64, 0);
+                    }
+                }
+            }
         };
         f32x16 b2init;                                               // conv2's bias / descale in the accumulator layout: requested BEFORE the residual pieces (in-order counter:
 #pragma unroll                                                       // whatever is requested behind them waits for their HBM latency)
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);
         p3_residual(0, 0);                                           // (they travel under epilogue 1 and phase 2)
+        p3_xd();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                             // every wave has left phase 3 of the previous item: the t1 region is free
         BN_TICK(1);                                                  // wait for the slowest wave
@@ -478,18 +499,29 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                 acc3[1] = acc3[0];
                 if (EAGLE_ABL_BNECK != 5) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                    for (int c = 0; c < (DSF ? 8 : 4); ++c) {
                         half8 Bh[2], Bl[2];
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            const char* p = t2b + (i * RH * TW) * TPS + c * 64;
-                            Bh[i] = *(const half8*)p; Bl[i] = *(const half8*)(p + 32);
+                            if (c < 4) {
+                                const char* p = t2b + (i * RH * TW) * TPS + c * 64;
+                                Bh[i] = *(const half8*)p; Bl[i] = *(const half8*)(p + 32);
+                            } else {
+                                Bh[i] = (half8)XD[DSF ? c - 4 : 0][i][0]; Bl[i] = (half8)XD[DSF ? c - 4 : 0][i][1];
+                            }
                         }
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            acc3[i] = BN_MFMA((half8)A3[c][0], Bh[i], acc3[i]);
-                            acc3[i] = BN_MFMA((half8)A3[c][0], Bl[i], acc3[i]);
-                            acc3[i] = BN_MFMA((half8)A3[c][1], Bh[i], acc3[i]);
+                            acc3[i] = BN_MFMA((half8)A3[c & 3][0], Bh[i], acc3[i]);
+                            acc3[i] = BN_MFMA((half8)A3[c & 3][0], Bl[i], acc3[i]);
+                            acc3[i] = BN_MFMA((half8)A3[c & 3][1], Bh[i], acc3[i]);
+                        }
+                        if (DSF && c < 4) {                 // rolling ring: the slot of chunk c takes chunk c + 4 (the downsample weights); it lands under the next three chunks' MFMAs
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int pt = 0; pt < 2; ++pt)
+                                A3[c][pt] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (unsigned)((((c + 4) * 2 + pt) * 8 + pass * 2 + mbw) * 1024 + lane * 16), 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
@@ -499,16 +531,20 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
 #pragma unroll
                 for (int ri = 0; ri < 2; ++ri) {
                     if (EAGLE_ABL_BNECK == 8) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+                    if constexpr (!DSF) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *(u32x4*)(strip + pstrip[i]) = rres[cur][ri][i];
+                        for (int i = 0; i < 4; ++i) *(u32x4*)(strip + pstrip[i]) = rres[DSF ? 0 : cur][DSF ? 0 : ri][DSF ? 0 : i];
+                    }
                     float v[4][4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[j][0] = acc3[ri][j * 4 + 0] * ds; v[j][1] = acc3[ri][j * 4 + 1] * ds;
                         v[j][2] = acc3[ri][j * 4 + 2] * ds; v[j][3] = acc3[ri][j * 4 + 3] * ds;
-                        const half4 rh = *(const half4*)run_hi(j), rl = *(const half4*)run_lo(j);
+                        if constexpr (!DSF) {
+                            const half4 rh = *(const half4*)run_hi(j), rl = *(const half4*)run_lo(j);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[j][r] = ((float)rh[r] + (float)rl[r]) * SPLIT_RX + v[j][r];
+                            for (int r = 0; r < 4; ++r) v[j][r] = ((float)rh[r] + (float)rl[r]) * SPLIT_RX + v[j][r];
+                        }
                     }
                     if (ri == 1 && pass + 1 < 4) { __builtin_amdgcn_sched_barrier(0); p3_bias(pass + 1); __builtin_amdgcn_sched_barrier(0); }      // (the accumulators have been read for the last time)
                     const bool inside = oy0 + q + RH * ri < a.H && ox0 + lx < a.W;
@@ -521,16 +557,25 @@ __global__ __launch_bounds__(TH * 64, 2) void bneck_split_kernel(BneckArgs a)
                         const float mm = split_absmax4(vmax, v[j][0], v[j][1], v[j][2], v[j][3]);
                         vmax = inside ? mm : vmax;
                     }
+                    u32x4 sd[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sd[i] = *(const u32x4*)(strip + pstrip[i]);
+                    __builtin_amdgcn_sched_barrier(0);                 // four distinct data registers, all read before the first store: no store's data register is rewritten behind it
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        __builtin_amdgcn_raw_buffer_store_b128(*(const u32x4*)(strip + pstrip[i]), yrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_y[ri][i], (pass * 2 + mbw) * 128, EAGLE_STORE_NT * 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(sd[i], yrs, EAGLE_ABL_BNECK == 3 ? OOB : poff_y[ri][i], (pass * 2 + mbw) * 128, EAGLE_STORE_NT * 2);
                     // HAZARD (found the hard way, round 6): a buffer_store of more than 64 bits reads its data VGPRs a few cycles AFTER it issues; a VALU write to
                     // one of them in the next issue slot corrupts the stored dword in some lanes.  hipcc's hazard recognizer inserts the wait state only when the
                     // store's soffset is an immediate — these stores carry the pass' channel block in an SGPR soffset, for which it assumes no hazard — and on gfx950 the
                     // corruption does happen once the CU's VMEM issue is back-pressured (two co-resident workgroups: 1 - 2 thousand wrong values per 66 M at B = 8,
                     // always the first dword of the item's LAST store, which the epilogue's v_cndmask on the saturation maximum overwrote; tools/probes/bneck_debug.py,
                     // tests/test_gpu_bneck.py::test_fused_bottleneck_forms_agree_with_co_resident_workgroups).  Three explicit wait states behind every block's stores.
+                    // The wait states are fenced on both sides: a bare asm statement is only ordered against memory operations, and hipcc did move VALU work
+                    // of the next block in front of it in the downsample-fused instantiation (v_max on the last store's first data register in the very next slot:
+                    // 16 wrong values per 0.4 G after a launch of another kernel, tools/probes/bneck_ds_probe.py).
+                    __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_nop 2" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -591,6 +636,7 @@ void bneck_launch(const BneckLaunch& L, hipStream_t s)
     if (L.x.f32 != 2 || L.res.f32 != 2 || L.y.f32 != 2) fail(EAGLE_E_INVALID, "fused bottleneck: split-format tensors required");
     if (L.x.c % 16 || L.y.c != 256 || L.res.c != 256 || L.res.h != L.x.h || L.res.w != L.x.w || L.y.h != L.x.h || L.y.w != L.x.w || L.res.n != L.x.n || L.y.n != L.x.n)
         fail(EAGLE_E_INVALID, "fused bottleneck: Cin = 16 k, Cmid = 64, Cout = 256, stride 1");
+    if (L.ds_fused && L.x.c != 64) fail(EAGLE_E_INVALID, "fused bottleneck: the downsample branch inside the kernel needs Cin = 64");
     BneckArgs a;
     a.x = L.x.p; a.xcs = L.x.cs * 2; a.xoff = L.x.off * 2; a.N = L.x.n; a.H = L.x.h; a.W = L.x.w; a.nch1 = L.x.c / 16;
     a.w1 = L.w1; a.w2 = L.w2; a.w3 = L.w3; a.b1 = L.b1; a.b2 = L.b2; a.b3 = L.b3; a.ds1 = L.ds1; a.ds2 = L.ds2; a.ds3 = L.ds3;
@@ -612,16 +658,16 @@ void bneck_launch(const BneckLaunch& L, hipStream_t s)
     // into MFMA registers, pixel-block-major; compile-time chunk counts: Cin = 256 and 64).  Measured on MI355X, B = 50, Cin = 256 (profiles/r06o_*, r06p_*): ring 1341 us,
     // direct 1380 (chunk-major) / 1411 (pixel-block-major) — phase 1 takes ~22 us per tile (x at ~4 TB/s at L2 level) in every form, ring two or five chunks deep included
     const char* re = getenv("EAGLE_BNECK_P1");
-    const int nch = (re && !strcmp(re, "direct")) ? (a.nch1 == 16 ? 16 : a.nch1 == 4 ? 4 : 0) : 0;
+    const int nch = (re && !strcmp(re, "direct") && !L.ds_fused) ? (a.nch1 == 16 ? 16 : a.nch1 == 4 ? 4 : 0) : 0;
     typedef void (*Kern)(BneckArgs);
     const char* pe = getenv("EAGLE_BNECK_LDS_PAD");                 // developer: extra LDS bytes per workgroup (forces ONE workgroup per CU in form 1)
     const int pad = pe ? atoi(pe) : 0;
     Kern fn; int lds, threads, wgs;
     if (form == 1) {
-        fn = nch == 16 ? (Kern)bneck_split_kernel<4, 1, 16> : nch == 4 ? (Kern)bneck_split_kernel<4, 1, 4> : (Kern)bneck_split_kernel<4, 1, 0>;
+        fn = L.ds_fused ? (Kern)bneck_split_kernel<4, 1, 0, true> : nch == 16 ? (Kern)bneck_split_kernel<4, 1, 16> : nch == 4 ? (Kern)bneck_split_kernel<4, 1, 4> : (Kern)bneck_split_kernel<4, 1, 0>;
         lds = (nch ? BneckGeom<4, 1>::REG : BneckGeom<4, 1>::LDS) + pad; threads = 256; wgs = we ? atoi(we) : 512;      // two persistent workgroups per CU (the B-direct form has no x ring in LDS)
     } else {
-        fn = nch == 16 ? (Kern)bneck_split_kernel<8, 2, 16> : nch == 4 ? (Kern)bneck_split_kernel<8, 2, 4> : (Kern)bneck_split_kernel<8, 2, 0>;
+        fn = L.ds_fused ? (Kern)bneck_split_kernel<8, 2, 0, true> : nch == 16 ? (Kern)bneck_split_kernel<8, 2, 16> : nch == 4 ? (Kern)bneck_split_kernel<8, 2, 4> : (Kern)bneck_split_kernel<8, 2, 0>;
         lds = nch ? BneckGeom<8, 2>::REG : BneckGeom<8, 2>::LDS; threads = 512; wgs = we ? atoi(we) : 256;            // one persistent workgroup per CU
     }
     ensure_max_dynamic_lds((const void*)fn, lds);

@@ -94,6 +94,7 @@ struct BneckLaunch {
     float ds1 = 1.f, ds2 = 1.f, ds3 = 1.f;
     unsigned* const* sat_slot = nullptr;
     unsigned long long* dbg = nullptr;       // developer timing builds only
+    bool ds_fused = false;                   // Cin = 64: w3 is the K = 128 image [W3 | downsample weights] (one scale), b3 = (b3 + bd) / ds3, `res` is ignored (pass y)
 };
 bool bneck_supported(const TView& x, int cmid, int cout);
 // w: folded fp32 weights [taps][cin][cout] (taps = 1 or 9)

@@ -402,9 +402,12 @@ struct Builder {
                     hwio[((size_t)t * cin + i) * cout + o] = (float)((double)w.data[((size_t)o * cin + i) * ks * ks + t] * scale[o]);
     }
     // One launch for a whole Bottleneck (bneck.hip): relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + res), kh.py:101-137
-    TView bottleneck(const TView& x, const std::string& q, const TView& res)
+    // ds_conv / ds_bn non-empty (block 0: Cin = 64): the 1 x 1 downsample branch of the shortcut is computed inside the launch (conv3 over K = 128 = [t2 | x], one weight
+    // scale, bias b3 + bd) and `res` is not read
+    TView bottleneck(const TView& x, const std::string& q, const TView& res, const std::string& ds_conv = "", const std::string& ds_bn = "")
     {
         BneckLaunch L;
+        const bool dsf = !ds_conv.empty();
         std::vector<float> hw, bs; int ci, co, ks;
         std::vector<_Float16> img;
         double flop = 0;
@@ -413,25 +416,34 @@ struct Builder {
         for (int k = 0; k < 3; ++k) {
             fold(q + cn[k], q + bnn[k], hw, bs, ci, co, ks);
             if (ks != want_ks[k] || ci != want_ci[k] || co != want_co[k]) fail(EAGLE_E_INVALID, "%s%s: not the Bottleneck shape of the fused kernel", q.c_str(), cn[k]);
+            if (k == 2 && dsf) {                            // conv3's K dimension extended by the downsample branch: rows 0 .. 63 = W3 (over t2), rows 64 .. 127 = Wd (over x)
+                std::vector<float> hwd, bd; int cid, cod, ksd;
+                fold(ds_conv, ds_bn, hwd, bd, cid, cod, ksd);
+                if (ksd != 1 || cid != 64 || cod != 256 || x.c != 64) fail(EAGLE_E_INVALID, "%s: not the 1x1 64->256 downsample of the fused kernel", ds_conv.c_str());
+                hw.insert(hw.end(), hwd.begin(), hwd.end());
+                for (int o = 0; o < 256; ++o) bs[o] = bs[o] + bd[o];
+                ci = 128;
+                flop += 2.0 * N * x.h * x.w * 256.0 * 64;
+            }
             float ds = 1.f;
             bneck_tile_weights(hw.data(), ks * ks, ci, co, img, &ds);
             bneck_scale_bias(bs, ds);
             const void* dw = net->upload(img.data(), img.size() * 2);
             const float* db = (const float*)net->upload(bs.data(), bs.size() * 4);
             if (k == 0) { L.w1 = dw; L.b1 = db; L.ds1 = ds; } else if (k == 1) { L.w2 = dw; L.b2 = db; L.ds2 = ds; } else { L.w3 = dw; L.b3 = db; L.ds3 = ds; }
-            flop += 2.0 * N * x.h * x.w * (double)co * ci * ks * ks;
+            flop += 2.0 * N * x.h * x.w * (double)co * (k == 2 ? 64 : ci) * ks * ks;
         }
-        L.x = x; L.res = res; L.y = act(x.h, x.w, 256);
+        L.x = x; L.y = act(x.h, x.w, 256); L.res = dsf ? L.y : res; L.ds_fused = dsf;
         L.sat_slot = &H->cur_sat;
         for (const TView* t : {&L.x, &L.y, &L.res})
             if ((size_t)t->n * t->h * t->w * t->cs * t->esize() >= ((size_t)1 << 31))
                 fail(EAGLE_E_INVALID, "%s: a %d x %d x %d x %d-channel tensor of this block reaches 2 GiB at a device batch of %d frames (32-bit tensor offsets); use a smaller EagleConfig.batch",
                      q.c_str(), t->n, t->h, t->w, t->cs, N);
         char label[64];
-        snprintf(label, sizeof(label), "bneck %d->64->256 @%dx%d%s", x.c, x.h, x.w, label_suffix);
+        snprintf(label, sizeof(label), "bneck %d->64->256%s @%dx%d%s", x.c, dsf ? "+ds" : "", x.h, x.w, label_suffix);
         net->names.emplace_back(new std::string(label));
         Op op; op.kind = Op::CONV; op.flop = flop; op.tag = net->names.back()->c_str(); op.stream = cur_stream;
-        op.bytes = (double)N * x.h * x.w * 4.0 * (x.c + 256 + (res.p == x.p ? 0 : 256)) + 4.0 * (x.c * 64 + 9 * 64 * 64 + 64 * 256);      // x once, y once (+ a separate residual tensor), weights once
+        op.bytes = (double)N * x.h * x.w * 4.0 * (x.c + 256 + ((dsf || res.p == x.p) ? 0 : 256)) + 4.0 * (x.c * 64 + 9 * 64 * 64 + 64 * 256 + (dsf ? 64 * 256 : 0));      // x once, y once (+ a separate residual tensor), weights once
         op.run = [L](hipStream_t s) { bneck_launch(L, s); };
         net->ops.push_back(op);
         return L.y;
@@ -528,13 +540,17 @@ static TView build_hrnet(Builder& B, const TView& x_in)
     B.release(x); x = x2;
     for (int b = 0; b < 4; ++b) {
         const std::string q = P + "layer1." + std::to_string(b) + ".";
-        TView res = x;
-        if (b == 0) res = B.conv(x, q + "downsample.0", q + "downsample.1", 1, 0, nullptr, nullptr, 0);
-        // round 6: the whole Bottleneck as one launch in the split family (EAGLE_BNECK_FUSED=0: the three launches of rounds 1-5)
+        // round 6: the whole Bottleneck as one launch in the split family (EAGLE_BNECK_FUSED=0: the three launches of rounds 1-5); block 0's downsample branch inside it
+        // (EAGLE_BNECK_DS=0: as its own launch, the residual read back)
         const char* fe = getenv("EAGLE_BNECK_FUSED");
-        if (B.prec == EAGLE_PREC_F32S && !(fe && atoi(fe) == 0) && bneck_supported(x, 64, 256)) {
-            TView y = B.bottleneck(x, q, res);
-            if (b == 0) B.release(res);
+        const char* de = getenv("EAGLE_BNECK_DS");
+        const bool fused = B.prec == EAGLE_PREC_F32S && !(fe && atoi(fe) == 0) && bneck_supported(x, 64, 256);
+        const bool dsf = fused && b == 0 && x.c == 64 && !(de && atoi(de) == 0);
+        TView res = x;
+        if (b == 0 && !dsf) res = B.conv(x, q + "downsample.0", q + "downsample.1", 1, 0, nullptr, nullptr, 0);
+        if (fused) {
+            TView y = dsf ? B.bottleneck(x, q, x, q + "downsample.0", q + "downsample.1") : B.bottleneck(x, q, res);
+            if (b == 0 && !dsf) B.release(res);
             B.release(x);
             x = y;
             continue;
@@ -2099,26 +2115,36 @@ int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int
 }
 
 int eagle_op_bottleneck(int device, const float* x, int n, int h, int w, int cin, const float* w1, const float* b1, const float* w2, const float* b2,
-                        const float* w3, const float* b3, const float* res, float* y, int reps, float* ms)
+                        const float* w3, const float* b3, const float* res, float* y, int reps, float* ms, const float* wd, const float* bd)
 {
     EagleHandle* hh = nullptr;
     API_BEGIN
     HIP_CHECK(hipSetDevice(device));
     if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !y || n < 1 || h < 1 || w < 1 || cin % 16 || cin < 16) fail(EAGLE_E_INVALID, "eagle_op_bottleneck: bad argument (Cin must be a multiple of 16)");
-    if (!res && cin != 256) fail(EAGLE_E_INVALID, "eagle_op_bottleneck: an identity shortcut needs Cin = 256");
+    if ((wd != nullptr) != (bd != nullptr) || (wd && (res || cin != 64))) fail(EAGLE_E_INVALID, "eagle_op_bottleneck: the in-kernel downsample branch takes (wd, bd) together, Cin = 64 and no residual tensor");
+    if (!res && !wd && cin != 256) fail(EAGLE_E_INVALID, "eagle_op_bottleneck: an identity shortcut needs Cin = 256");
     Net net;
     BneckLaunch L;
     to_dev(net, EAGLE_PREC_F32S, x, n, h, w, cin, cin, L.x);
     if (res) to_dev(net, EAGLE_PREC_F32S, res, n, h, w, 256, 256, L.res); else L.res = L.x;
-    L.y = L.res; L.y.p = net.get((size_t)n * h * w * 256 * 4);
+    L.y = L.x; L.y.c = L.y.cs = 256; L.y.off = 0; L.y.p = net.get((size_t)n * h * w * 256 * 4);
+    if (wd) L.res = L.y;                                    // (not read)
     std::vector<_Float16> img;
     bneck_tile_weights(w1, 1, cin, 64, img, &L.ds1); L.w1 = net.upload(img.data(), img.size() * 2);
     bneck_tile_weights(w2, 9, 64, 64, img, &L.ds2); L.w2 = net.upload(img.data(), img.size() * 2);
-    bneck_tile_weights(w3, 1, 64, 256, img, &L.ds3); L.w3 = net.upload(img.data(), img.size() * 2);
-    std::vector<float> sb1(b1, b1 + 64), sb2(b2, b2 + 64), sb3(b3, b3 + 256);
+    std::vector<float> w3x(w3, w3 + 64 * 256), sb3(b3, b3 + 256);
+    if (wd) {                                               // K = 128: [W3 | Wd], bias b3 + bd
+        w3x.insert(w3x.end(), wd, wd + 64 * 256);
+        for (int o = 0; o < 256; ++o) sb3[o] = sb3[o] + bd[o];
+        L.ds_fused = true;
+    }
+    bneck_tile_weights(w3x.data(), 1, wd ? 128 : 64, 256, img, &L.ds3); L.w3 = net.upload(img.data(), img.size() * 2);
+    std::vector<float> sb1(b1, b1 + 64), sb2(b2, b2 + 64);
     bneck_scale_bias(sb1, L.ds1); bneck_scale_bias(sb2, L.ds2); bneck_scale_bias(sb3, L.ds3);
     L.b1 = (const float*)net.upload(sb1.data(), 64 * 4); L.b2 = (const float*)net.upload(sb2.data(), 64 * 4); L.b3 = (const float*)net.upload(sb3.data(), 256 * 4);
     if (getenv("EAGLE_BNECK_TIMING")) L.dbg = (unsigned long long*)net.get(8192 * 8 * 8);      // (developer timing builds: -DEAGLE_BNECK_TIMING)
+    unsigned* op_sat = nullptr; unsigned* const* op_sat_slot = &op_sat;
+    if (getenv("EAGLE_BNECK_OPSAT")) { op_sat = (unsigned*)net.get(sizeof(unsigned) * (size_t)n); L.sat_slot = op_sat_slot; }      // developer: the per-frame saturation counters the pipeline passes
     bneck_launch(L, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     if (L.dbg) {

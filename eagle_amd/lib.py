@@ -128,7 +128,7 @@ def load():
     L.eagle_get_timings.argtypes = [vp, C.POINTER(EagleTimings)]
     L.eagle_get_kernel_times.argtypes = [vp, C.POINTER(EagleKernelTime), i32, C.POINTER(i32)]
     L.eagle_op_conv2d.argtypes = [i32, i32, fp, i32, i32, i32, i32, fp, fp, i32, i32, i32, i32, fp, fp, i32, fp]
-    L.eagle_op_bottleneck.argtypes = [i32, fp, i32, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32, fp]
+    L.eagle_op_bottleneck.argtypes = [i32, fp, i32, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, i32, fp, fp, fp]
     L.eagle_op_fuse_sum.argtypes = [i32, i32, fp, i32, i32, i32, i32, i32, C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, fp]
     L.eagle_op_preprocess.argtypes = [i32, i32, u8p, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
     L.eagle_op_preprocess_lb.argtypes = [i32, i32, u8p, i32, i32, i32, i32, i32, fp, fp, C.POINTER(i32)]
@@ -490,7 +490,7 @@ def op_conv2d(x, w_hwio, bias, stride=1, pre=0, r1=None, r2=None, post=0, precis
     return y
 
 
-def op_bottleneck(x, w1, b1, w2, b2, w3, b3, res=None, reps=0, device=0):
+def op_bottleneck(x, w1, b1, w2, b2, w3, b3, res=None, reps=0, device=0, wd=None, bd=None):
     """One fused Bottleneck launch of the split family (include/eagle.h eagle_op_bottleneck; csrc/bneck.hip).  Returns y, or (y, ms per launch) when reps > 0."""
     L = load()
     x = np.ascontiguousarray(x, np.float32)
@@ -500,7 +500,9 @@ def op_bottleneck(x, w1, b1, w2, b2, w3, b3, res=None, reps=0, device=0):
     res = None if res is None else np.ascontiguousarray(res, np.float32)
     y = np.empty((n, h, w, 256), np.float32)
     ms = C.c_float(0)
-    rc = L.eagle_op_bottleneck(device, _fp(x), n, h, w, cin, *[_fp(a) for a in arrs], _fp(res), _fp(y), int(reps), C.byref(ms))
+    wd = None if wd is None else np.ascontiguousarray(wd, np.float32)      # the 1x1 downsample branch [1][1][64][256] computed inside the launch (block 0)
+    bd = None if bd is None else np.ascontiguousarray(bd, np.float32)
+    rc = L.eagle_op_bottleneck(device, _fp(x), n, h, w, cin, *[_fp(a) for a in arrs], _fp(res), _fp(y), int(reps), C.byref(ms), _fp(wd), _fp(bd))
     if rc:
         raise EagleError(f"eagle_op_bottleneck failed ({rc}): {L.eagle_last_error(None).decode()}")
     return (y, ms.value) if reps > 0 else y

@@ -286,7 +286,8 @@ int eagle_op_conv2d(int device, int precision, const float* x, int n, int h, int
  * conv2 3x3 64->64, conv3 1x1 64->256, BatchNorm already folded into (w, b); weights HWIO ([1][1][Cin][64], [3][3][64][64], [1][1][64][256]); res = NULL: the
  * identity shortcut (Cin = 256).  reps > 0: *ms = average duration of `reps` further launches (HIP events). */
 int eagle_op_bottleneck(int device, const float* x, int n, int h, int w, int cin, const float* w1, const float* b1, const float* w2, const float* b2,
-                        const float* w3, const float* b3, const float* res, float* y, int reps, float* ms);
+                        const float* w3, const float* b3, const float* res, float* y, int reps, float* ms,
+                        const float* wd /* NULL, or the 1x1 downsample branch [1][1][64][256] computed inside the launch (Cin = 64, res = NULL) */, const float* bd);
 int eagle_op_fuse_sum(int device, int precision, const float* base, int n, int H, int W, int c, int n_up,
                       const float* const* ups, const int* up_h, const int* up_w, int relu, float* y);
 int eagle_op_preprocess(int device, int precision, const uint8_t* bgr, int n, int h, int w, int det_imgsz,

@@ -108,3 +108,51 @@ def test_fused_bottleneck_forms_agree_with_co_resident_workgroups(monkeypatch):
         monkeypatch.setenv("EAGLE_BNECK_P1", p1)
         y1 = lib.op_bottleneck(x, *ws)
         assert np.array_equal(y0, y1), f"form 1 ({wgs} workgroups, phase 1 {p1}) differs from form 0 in {int((y0 != y1).sum())} values"
+
+
+@pytest.mark.parametrize("form", ["0", "1"])
+@pytest.mark.parametrize("wgs", ["256", "8"])
+@pytest.mark.parametrize("shape", SHAPES + [(1, 135, 240)])
+def test_fused_bottleneck_with_the_downsample_branch_inside(shape, wgs, form, monkeypatch):
+    """Block 0 of layer 1 (kh.py:328): the shortcut is a 1 x 1 convolution 64 -> 256 + BatchNorm of x.  With (wd, bd) the launch computes it itself — conv3 over K = 128 =
+    [t2 | x], both weight sets on one power-of-two scale, bias b3 + bd, x's inner pixels as B-direct fragments — instead of reading a residual tensor: against the oracle's
+    FOUR convolutions, and against the same launch fed with the oracle's downsample output as a residual tensor."""
+    from eagle_amd import lib
+    from oracle import prims as P
+    monkeypatch.setenv("EAGLE_BNECK_WGS", wgs)
+    monkeypatch.setenv("EAGLE_BNECK_FORM", form)
+    n, h, w = shape
+    x = np.maximum(_rand((n, h, w, 64), 101), 0)
+    ws = _weights(64, 102)
+    wd = _rand((1, 1, 64, 256), 108, (2.0 / 64) ** 0.5 * 0.37)      # another magnitude than W3: the common scale must serve both
+    bd = _rand((256,), 109, 0.1)
+    res = P.conv2d(x, wd, bd, stride=1, pre=0, r1=None, r2=None, post=0)
+    ref = _oracle(x, ws, res)
+    got = lib.op_bottleneck(x, *ws, wd=wd, bd=bd)
+    scale = max(np.abs(ref).max(), 1e-6)
+    assert np.abs(ref - got).max() / scale < BNECK_TOL + F32S_TOL, f"fused bottleneck + downsample error {np.abs(ref - got).max() / scale}"
+    via_tensor = lib.op_bottleneck(x, *ws, res=res)
+    assert np.abs(via_tensor - got).max() / scale < BNECK_TOL
+
+
+def test_fused_bottleneck_after_a_launch_of_another_kernel(monkeypatch):
+    """The second appearance of the store-data hazard (csrc/bneck.hip, phase 3): in the downsample-fused instantiation hipcc had moved the next block's VALU work in
+    front of the explicit wait states, and 16 values per 0.4 G came out wrong — but only when the launch followed ANOTHER kernel (in the pipeline: the stem), never in a
+    sequence of Bottleneck launches, which is why every operator-level test passed while whole frames failed.  Here a convolution over NaNs precedes each launch; both
+    shortcut forms, full-size maps, against a result computed first.  (tools/isa_store_hazard.py is the static check of the same rule, tests/test_isa_lint.py.)"""
+    from eagle_amd import lib
+    from oracle import prims as P
+    x = np.maximum(_rand((4, 135, 240, 64), 121), 0)
+    ws = _weights(64, 122)
+    wd = _rand((1, 1, 64, 256), 123, (2.0 / 64) ** 0.5 * 0.5)
+    bd = _rand((256,), 124, 0.1)
+    res = P.conv2d(x[:1], wd, bd, stride=1, pre=0, r1=None, r2=None, post=0)
+    first = lib.op_bottleneck(x, *ws, wd=wd, bd=bd)
+    scale = np.abs(first).max()
+    assert np.abs(lib.op_bottleneck(x[:1], *ws, res=res) - first[:1]).max() / scale < BNECK_TOL
+    poison_x = np.full((4, 135, 240, 64), np.nan, np.float32)
+    poison_w = np.full((3, 3, 64, 64), np.nan, np.float32)
+    for rep in range(6):
+        lib.op_conv2d(poison_x, poison_w, np.zeros(64, np.float32), 2, 0, None, None, 1, lib.PREC_F32S)
+        again = lib.op_bottleneck(x, *ws, wd=wd, bd=bd)
+        assert np.array_equal(first, again), f"repetition {rep}: {int((first != again).sum())} values differ after a launch of another kernel"

@@ -14,6 +14,8 @@
 #   sq               SQ stall counters (tools/pmc_sq.sh)
 #   bneck            fused-Bottleneck probe: both tile forms, both phase-1 forms, Cin 256 / 64 (tools/probes/bneck_probe.py)
 #   bneck_ab         whole-pipeline A/B EAGLE_BNECK_FUSED=0/1, three alternating pairs
+#   bneck_ds_ab      whole-pipeline A/B EAGLE_BNECK_DS=0/1 (block 0's downsample branch inside the fused launch), three alternating pairs
+#   bneck_ds         operator-level and pipeline probes of the downsample-fused launch (tools/probes/bneck_ds_probe.py, bneck_ds_pipeline_probe.py)
 #   cpu_sweep        cpu_baseline thread sweep (16 32 64 128)
 tag=${1:-x}; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
@@ -40,6 +42,11 @@ for step in "$@"; do
            for rep in 1 2 3; do for f in 0 1; do echo "EAGLE_BNECK_FUSED=$f rep $rep" >> $L
              EAGLE_BNECK_FUSED=$f timeout 600 python bench.py --no-extras --no-cpu-baseline --latency-calls 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'frames/s', d['ms_per_step'], 'ms/step; conv family', d['roofline']['conv_ms_per_step'], 'ms, frac', d['roofline']['frac'])" >> $L 2>&1
            done; done; cat $L ;;
+    bneck_ds_ab) L=$O/bneck_ds_pipeline_ab.log; : > $L
+           for rep in 1 2 3; do for f in 0 1; do echo "EAGLE_BNECK_DS=$f rep $rep" >> $L
+             EAGLE_BNECK_DS=$f timeout 600 python bench.py --no-extras --no-cpu-baseline --latency-calls 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'frames/s', d['ms_per_step'], 'ms/step; conv family', d['roofline']['conv_ms_per_step'], 'ms, frac', d['roofline']['frac'])" >> $L 2>&1
+           done; done; cat $L ;;
+    bneck_ds) timeout 600 python tools/probes/bneck_ds_probe.py > $O/bneck_ds_probe.log 2>&1; timeout 600 python tools/probes/bneck_ds_pipeline_probe.py > $O/bneck_ds_pipeline_probe.log 2>&1; tail -4 $O/bneck_ds_probe.log $O/bneck_ds_pipeline_probe.log ;;
     cpu_sweep) for t in 16 32 64 128; do echo "threads $t" >> $O/cpu_baseline_thread_sweep.txt; timeout 600 python bench.py --cpu-baseline-only --cpu-threads $t --cpu-frames 40 2>/dev/null | tail -1 >> $O/cpu_baseline_thread_sweep.txt; done; cat $O/cpu_baseline_thread_sweep.txt ;;
     *) echo "unknown step $step" ;;
   esac

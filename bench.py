@@ -483,7 +483,7 @@ def main():
         """A second handle of another precision family on frames that are already resident: frames/s (K steps of Bf in one call), the
         convolution family's HIP-event roofline, optionally the records of the first `want_records` frames.  det_prec None: detector in `prec`."""
         hf = lib.Handle(device=dev_index, frame_h=hw[0], frame_w=hw[1], det_variant=det, det_imgsz=imgsz, batch=Bf, precision=lib.PRECISIONS[prec],
-                        det_precision=lib.PRECISIONS[det_prec or prec] + 1)
+                        det_precision=lib.DET_PREC_MIXED if det_prec == "mixed" else lib.PRECISIONS[det_prec or prec] + 1)
         weights.load_into(hf, sd or [hs, ys])
         nf = max(Bf, nframes // Bf * Bf)
         of = np.zeros(nf, lib.RESULT_DTYPE)
@@ -492,7 +492,7 @@ def main():
         hf.process_device(d_frames, nf, of)
         dtf = time.perf_counter() - t1
         mixed = det_prec is not None and det_prec != prec
-        r = {"dtype": prec if not mixed else f"{prec} key-points + {det_prec} detector", "value": round(nf / dtf, 2), "unit": "frames/s", "frames": nf, "frames_per_step": Bf}
+        r = {"dtype": prec if not mixed else f"{prec} key-points + {'f32s trunk / f32 last C2f per level + Detect' if det_prec == 'mixed' else det_prec} detector", "value": round(nf / dtf, 2), "unit": "frames/s", "frames": nf, "frames_per_step": Bf}
         if not mixed:
             fms, fflop, fnc, _, fsteps = profile(hf, d_frames, Bf, 1)
             ach = fflop / (fms * 1e-3) / 1e12 if fms > 0 else 0.0
@@ -556,7 +556,7 @@ def main():
         B3 = 25
         n3 = max(B3, a.cfg3_frames // B3 * B3)
         yl = weights.make_yolo_state_dict("l", 0)
-        base3 = synth.clip(seed=0, n=10, h=1080, w=1920)
+        base3 = synth.clip(seed=0, n=40, h=1080, w=1920)      # 40 distinct frames (10 until round 5): the mixed detector's id counters below compare all of them
         clip3 = np.concatenate([base3] * (-(-n3 // len(base3))))[:n3]
         d3 = h.upload(clip3)
         del clip3
@@ -564,10 +564,21 @@ def main():
         runs = [("f32s", None), ("f16", None)] if a.precision == "f32s" else [(a.precision, None)]
         if a.precision == "f32s" and det_prec_name == "f32":
             runs.insert(0, ("f32s", "f32"))              # the default configuration: 210 of the 544 GFLOP per frame in the exact family
+        if a.precision == "f32s" and det_prec_name == "f32":
+            runs.insert(1, ("f32s", "mixed"))            # VERDICT r5 task 7: split trunk, exact last C2f per level + Detect — measured against the id contract below
+        rec3 = {}
         for pr, dp in runs:
-            r3, _ = family_run(pr, n3, B3, d3, hw=(1080, 1920), det="l", imgsz=960, sd=[hs, yl], det_prec=dp)
-            cfg3["default" if dp else pr] = r3
+            r3, rec3[dp or pr] = family_run(pr, n3, B3, d3, hw=(1080, 1920), det="l", imgsz=960, sd=[hs, yl], det_prec=dp, want_records=len(base3))
+            cfg3["default" if dp == "f32" else "mixed_detector" if dp == "mixed" else pr] = r3
             log(f"cfg3 {r3['dtype']}: {r3['value']} frames/s")
+        if "f32" in rec3:
+            # integer-field differences against the default configuration (exact detector; the key-point network is the same split family in all three, so every count is the detector's)
+            cfg3["parity_counters_vs_default"] = {k: int_field_diffs(rec3[k], rec3["f32"]) for k in ("mixed", "f32s") if k in rec3}
+            cfg3["parity_counters_vs_default"]["frames"] = len(base3)
+            cfg3["mixed_detector"]["kept"] = False
+            cfg3["mixed_detector"]["note"] = ("EAGLE_DET_PREC_MIXED is selectable and NOT the default: VERDICT r5 task 7 keeps it only if every counter is 0 "
+                                              "(see parity_counters_vs_default.mixed)")
+            log(f"cfg3 id counters vs the exact detector: {json.dumps(cfg3['parity_counters_vs_default'])}")
         h.free(d3)
 
     realistic = None

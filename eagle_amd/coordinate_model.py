@@ -34,7 +34,8 @@ class CoordinateModel:
         self.batch = batch
         # detector_precision=None: the library's default — with precision="f32s" the detector runs in the exact fp32 family (boxes, confidences,
         # classes, NMS order and hence every detection-index id equal the fp32 reference arithmetic bit for bit), otherwise in `precision`
-        dp = {} if detector_precision is None else {"det_precision": lib.PRECISIONS[detector_precision] + 1}
+        # "mixed": split-family trunk, exact last C2f per level + Detect (EAGLE_DET_PREC_MIXED: measured, does not keep the exact family's ids; never a default)
+        dp = {} if detector_precision is None else {"det_precision": lib.DET_PREC_MIXED if detector_precision == "mixed" else lib.PRECISIONS[detector_precision] + 1}
         self.handle = lib.Handle(device=device, frame_h=frame_hw[0], frame_w=frame_hw[1], det_variant=detector,
                                  det_imgsz=det_imgsz, batch=batch, letterbox=letterbox,
                                  precision=lib.PRECISIONS[precision],

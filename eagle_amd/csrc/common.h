@@ -112,6 +112,7 @@ struct FuseUp { TView z; };
 void fuse_sum_launch(const TView& base, const FuseUp* ups, int n_up, int relu, const TView& y, hipStream_t s, unsigned* sat = nullptr);   // sat: as ConvArgs::sat
 void maxpool5_launch(const TView& x, const TView& y, hipStream_t s);
 void upsample2_launch(const TView& x, const TView& y, hipStream_t s);
+void split_to_f32_launch(const TView& x, const TView& y, hipStream_t s);      // split fp32 -> fp32, exact (the mixed detector's seam)
 
 // logits: fp32 view [n,h,w,64]; parts: [n][chunks][64]
 void heat_argmax_launch(const TView& logits, ArgmaxPart* parts, int chunks, hipStream_t s);

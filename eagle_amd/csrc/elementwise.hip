@@ -385,6 +385,28 @@ void upsample2_launch(const TView& x, const TView& y, hipStream_t s)
     HIP_CHECK(hipGetLastError());
 }
 
+// split fp32 -> fp32 (the seam of the mixed-precision detector, EAGLE_DET_PREC_MIXED: trunk in the split family, the last C2f of every level and Detect in the
+// exact family): value = (hi + lo) / 16, exact — hi + lo has at most 22 significant bits.  x, y: same n, h, w, c; any channel slices.
+__global__ __launch_bounds__(256) void split_to_f32_kernel(TView x, TView y)
+{
+    const int groups = x.c / 8;
+    const size_t total = (size_t)x.n * x.h * x.w * groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const size_t pix = i / groups;
+        Vec<SplitT> v; v.load(x.p, pix * x.cs + x.off + g * 8);
+        float* o = (float*)y.p + pix * y.cs + y.off + g * 8;
+        *(float4*)o = make_float4(v.v[0] * 0.0625f, v.v[1] * 0.0625f, v.v[2] * 0.0625f, v.v[3] * 0.0625f);
+        *(float4*)(o + 4) = make_float4(v.v[4] * 0.0625f, v.v[5] * 0.0625f, v.v[6] * 0.0625f, v.v[7] * 0.0625f);
+    }
+}
+void split_to_f32_launch(const TView& x, const TView& y, hipStream_t s)
+{
+    const size_t total = (size_t)x.n * x.h * x.w * (x.c / 8);
+    hipLaunchKernelGGL(split_to_f32_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, x, y);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K5: per-channel first maximum of sigmoid(logits) over a pixel range (KeypointModel.get_keypoints,
 //     eagle/models/keypoint_hrnet.py:581-593: np.argmax of the sigmoid map = first maximum, row-major).

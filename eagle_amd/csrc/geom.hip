@@ -22,6 +22,9 @@ namespace eagle {
 #define RNG_N 65536        // precomputed draws of cv::RNG(-1): the stream does not depend on the data
 #define DEPS 2.220446049250313e-16
 
+// Ordering point between the lanes of ONE wave working on shared LDS data: the LDS operations of a wave execute in issue order, so all that is needed is that the
+// compiler neither moves LDS accesses across the point nor keeps values in registers over it.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define JROT(x, y) do { const double g_ = (x), h_ = (y); (x) = g_ - s * (h_ + g_ * tau); (y) = h_ + s * (g_ - h_ * tau); } while (0)
 __device__ __forceinline__ float reproj_err1(const double* src, const double* dst, int i, const double* H)
 {
@@ -172,25 +175,42 @@ __device__ __forceinline__ void lm_point(const double* src, const double* dst, i
         b[6] = -Mx * ww * yi; b[7] = -My * ww * yi;
     }
 }
-__device__ int solve8(double A[8][8], double b[8], double x[8])
+// 8 x 8 solve of the LM step by one WAVE on the augmented system M in LDS: lane (r, j) = (lane >> 3, lane & 7) owns entry M[r][j], the lanes of column 7 also the
+// right-hand side; the pivot choice and the back substitution are computed redundantly by every lane (uniform control flow).  Per value the operations of
+// oracle/eo_prims.c::eo_solve8 in the same order (one thread walked the system until round 6: dynamic row indices on a private array = the 385 scratch instructions
+// that were left in find_homography_block, and ~15 us per solve).  Result in x (LDS); every lane returns the same flag.
+__device__ int solve8_wave(double (*M)[9], double* x, int lane)
 {
-    double M[8][9];
-    for (int i = 0; i < 8; ++i) { for (int j = 0; j < 8; ++j) M[i][j] = A[i][j]; M[i][8] = b[i]; }
+    const int r = lane >> 3, j = lane & 7;
     for (int c = 0; c < 8; ++c) {
-        int p = c;
-        for (int r = c + 1; r < 8; ++r) if (fabs(M[r][c]) > fabs(M[p][c])) p = r;
-        if (fabs(M[p][c]) < 1e-300) return 0;
-        if (p != c) for (int j = 0; j < 9; ++j) { const double t = M[c][j]; M[c][j] = M[p][j]; M[p][j] = t; }
-        for (int r = c + 1; r < 8; ++r) {
-            const double f = M[r][c] / M[c][c];
-            for (int j = c; j < 9; ++j) M[r][j] -= f * M[c][j];
+        int p = c; double bestv = fabs(M[c][c]);
+        for (int r2 = c + 1; r2 < 8; ++r2) { const double v = fabs(M[r2][c]); if (v > bestv) { bestv = v; p = r2; } }
+        if (bestv < 1e-300) return 0;
+        WAVE_SYNC();                                       // every lane has read column c
+        if (p != c) {
+            if (lane < 9) { const double t = M[c][lane]; M[c][lane] = M[p][lane]; M[p][lane] = t; }
+            WAVE_SYNC();
         }
+        const double f = M[r][c] / M[c][c];
+        const double mj = M[c][j], mr = M[r][j], m8c = M[c][8], m8r = M[r][8];
+        WAVE_SYNC();                                       // every lane has read its operands
+        if (r > c && j >= c) M[r][j] = mr - f * mj;
+        if (r > c && j == 7) M[r][8] = m8r - f * m8c;
+        WAVE_SYNC();
     }
+    double xr[8];
+#pragma unroll
     for (int i = 7; i >= 0; --i) {
         double s = M[i][8];
-        for (int j = i + 1; j < 8; ++j) s -= M[i][j] * x[j];
-        x[i] = s / M[i][i];
+#pragma unroll
+        for (int j2 = i + 1; j2 < 8; ++j2) s -= M[i][j2] * xr[j2];
+        xr[i] = s / M[i][i];
     }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = xr[i];
+    }
+    WAVE_SYNC();
     return 1;
 }
 __device__ const double D_P10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5,
@@ -201,21 +221,23 @@ __device__ const double D_P10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1
 struct HomoShared {
     double src[2 * EAGLE_MAX_KP], dst[2 * EAGLE_MAX_KP];
     double s2[2 * EAGLE_MAX_KP], d2[2 * EAGLE_MAX_KP];
-    double cand[POST_T][9];
+    union {
+        double cand[POST_T][9];                  // phase (c) -> (d): the 4-point models of the round's attempts
+        unsigned short jump[3][RANSAC_WIN];      // phase (b): next^4, next^16, next^64 of the attempt chain (dead before (c) writes cand)
+    };
     double best[9];
     double jA[9][9], jV[9][9], jd[9], jb[9], jz[9], jH[9];      // the all-inlier fit: 9 x 9 LtL (upper triangle), eigenvectors, Jacobi vectors, result
     int jok;
     double lm_r[2 * EAGLE_MAX_KP], lm_rn[2 * EAGLE_MAX_KP], lm_J[16 * EAGLE_MAX_KP];
-    double lm_A[8][8], lm_g[8], lm_h[8], lm_hn[8];
+    double lm_A[8][8], lm_g[8], lm_h[8], lm_hn[8], lm_M[8][9], lm_d[8];
     double lm_S;
     int lm_lambda, lm_flag;            // flag: 0 = solve failed (retry), 1 = candidate ready, 2 = improved, 3 = stop
-    int subset[POST_T][4];
-    int good[POST_T];
     alignas(16) unsigned char code[POST_T];   // per attempt: 255 degenerate subset (rejected), 254 model failed, else inlier count
     unsigned char mask[EAGLE_MAX_KP];
     int niters, max_good, ok, stop, iter, fail_run, ni;
-    int pos, natt, newpos;             // cursor into the precomputed MWC stream; attempts parsed this round
-    unsigned char draw[RANSAC_WIN + 256];   // the round's slice of the random stream, already reduced modulo the point count
+    int pos, newpos;                   // cursor into the precomputed MWC stream
+    int wlive[POST_T / 64];            // attempts of the round per wave
+    alignas(4) unsigned char draw[RANSAC_WIN + 256];   // the round's slice of the random stream, already reduced modulo the point count
     unsigned tuple[RANSAC_WIN];        // 4 packed point indices of the sampling attempt starting at window position w
     unsigned char len[RANSAC_WIN];     // draws it consumes (0 = stream exhausted)
     int start[POST_T];
@@ -263,8 +285,11 @@ __device__ int dlt_homography_block(HomoShared& S, const double* src, const doub
         S.jV[a][b] = (a == b) ? 1.0 : 0.0;
     }
     __syncthreads();
+    // The sweeps run in wave 0 alone (round 6): a rotation's work is 19 lanes wide and its parameters are a dependent chain of fp64 divisions and square roots, so the
+    // other three waves only added two workgroup barriers per rotation (~250 rotations per fit: 200 us of the kernel); between the lanes of one wave WAVE_SYNC orders.
+    if (tid < 64) {
     if (tid < 9) { S.jd[tid] = S.jb[tid] = S.jA[tid][tid]; S.jz[tid] = 0.0; }
-    __syncthreads();
+    WAVE_SYNC();
     for (int sweep = 1; sweep <= 50; ++sweep) {
         double smm = 0.0;
         for (int p = 0; p < 8; ++p)
@@ -276,9 +301,9 @@ __device__ int dlt_homography_block(HomoShared& S, const double* src, const doub
                 const double apq = S.jA[p][q], dp = S.jd[p], dq = S.jd[q];
                 const double g = 100.0 * fabs(apq);
                 if (sweep > 4 && fabs(dp) + g == fabs(dp) && fabs(dq) + g == fabs(dq)) {
-                    __syncthreads();                       // every thread has read a[p][q]
+                    WAVE_SYNC();                       // every thread has read a[p][q]
                     if (tid == 0) S.jA[p][q] = 0.0;
-                    __syncthreads();
+                    WAVE_SYNC();
                 } else if (fabs(apq) > tresh) {
                     double h = dq - dp, t;
                     if (fabs(h) + g == fabs(h)) {
@@ -290,7 +315,7 @@ __device__ int dlt_homography_block(HomoShared& S, const double* src, const doub
                     }
                     const double c = 1.0 / sqrt(1.0 + t * t), s = t * c, tau = s / (1.0 + c);
                     h = t * apq;
-                    __syncthreads();                       // every thread has read a[p][q], d[p], d[q]
+                    WAVE_SYNC();                       // every thread has read a[p][q], d[p], d[q]
                     if (tid == 0) {
                         S.jz[p] -= h; S.jz[q] += h; S.jd[p] -= h; S.jd[q] += h; S.jA[p][q] = 0.0;
                     } else if (tid >= 1 && tid <= 9) {     // the rotation on the other entries of rows / columns p, q of the upper triangle
@@ -302,13 +327,15 @@ __device__ int dlt_homography_block(HomoShared& S, const double* src, const doub
                         const int j = tid - 16;
                         JROT(S.jV[j][p], S.jV[j][q]);
                     }
-                    __syncthreads();
+                    WAVE_SYNC();
                 }
             }
-        __syncthreads();                                   // the sweep's last pairs may have passed without a barrier: every thread has read S.jd[p], S.jd[q] (they steer the branches above)
+        WAVE_SYNC();                                   // the sweep's last pairs may have passed without a barrier: every thread has read S.jd[p], S.jd[q] (they steer the branches above)
         if (tid < 9) { S.jb[tid] += S.jz[tid]; S.jd[tid] = S.jb[tid]; S.jz[tid] = 0.0; }
-        __syncthreads();
+        WAVE_SYNC();
     }
+    }
+    __syncthreads();
     int m = 0;
     double dm = S.jd[0];
     for (int i = 1; i < 9; ++i) if (S.jd[i] < dm) { dm = S.jd[i]; m = i; }
@@ -332,67 +359,79 @@ __device__ int dlt_homography_block(HomoShared& S, const double* src, const doub
     return ok;
 }
 
-// refine S.best over the ni inlier points in S.s2/S.d2 (all threads call; barriers inside)
+// refine S.best over the ni inlier points in S.s2/S.d2 (all threads call; wave 0 works — n <= 87 points, an 8 x 8 system: nothing here is wider than a wave, and
+// the ~10 workgroup barriers per iteration cost more than the arithmetic — and a barrier closes)
 __device__ void lm_refine_block(HomoShared& S, int n, int max_iters)
 {
     const int tid = threadIdx.x;
-    if (tid < 8) S.lm_h[tid] = S.best[tid];
-    __syncthreads();
-    for (int i = tid; i < n; i += POST_T) lm_point(S.s2, S.d2, i, S.lm_h, S.lm_r, S.lm_J);
-    __syncthreads();
-    if (tid == 0) {
-        double Ssum = 0;
-        for (int i = 0; i < 2 * n; ++i) Ssum += S.lm_r[i] * S.lm_r[i];
-        S.lm_S = Ssum; S.lm_lambda = -3;
-    }
-    __syncthreads();
-    for (int it = 0; it < max_iters; ++it) {
-        if (tid < 64) {
-            const int a = tid >> 3, b = tid & 7;
-            double acc = 0;
-            for (int i = 0; i < 2 * n; ++i) acc += S.lm_J[(size_t)i * 8 + a] * S.lm_J[(size_t)i * 8 + b];
-            S.lm_A[a][b] = acc;
-        } else if (tid < 72) {
-            const int a = tid - 64;
-            double acc = 0;
-            for (int i = 0; i < 2 * n; ++i) acc += S.lm_J[(size_t)i * 8 + a] * S.lm_r[i];
-            S.lm_g[a] = acc;
+    if (tid < 64) {
+        if (tid < 8) S.lm_h[tid] = S.best[tid];
+        WAVE_SYNC();
+        for (int i = tid; i < n; i += 64) lm_point(S.s2, S.d2, i, S.lm_h, S.lm_r, S.lm_J);
+        WAVE_SYNC();
+        if (tid == 0) {
+            double Ssum = 0;
+            for (int i = 0; i < 2 * n; ++i) Ssum += S.lm_r[i] * S.lm_r[i];
+            S.lm_S = Ssum; S.lm_lambda = -3;
         }
-        __syncthreads();
-        int improved = 0;
-        for (int tries = 0; tries < 16 && !improved; ++tries) {
-            if (tid == 0) {
-                double Ap[8][8], d[8], gm[8];
-                const double lam = D_P10[S.lm_lambda + 16];
-                for (int a = 0; a < 8; ++a) { for (int b = 0; b < 8; ++b) Ap[a][b] = S.lm_A[a][b]; Ap[a][a] += lam * S.lm_A[a][a]; gm[a] = -S.lm_g[a]; }
-                if (!solve8(Ap, gm, d)) { S.lm_lambda = S.lm_lambda + 1 > 16 ? 16 : S.lm_lambda + 1; S.lm_flag = 0; }
-                else { for (int k = 0; k < 8; ++k) S.lm_hn[k] = S.lm_h[k] + d[k]; S.lm_flag = 1; }
-            }
-            __syncthreads();
-            if (S.lm_flag == 0) { __syncthreads(); continue; }          // uniform
-            for (int i = tid; i < n; i += POST_T) lm_point(S.s2, S.d2, i, S.lm_hn, S.lm_rn, nullptr);
-            __syncthreads();
-            if (tid == 0) {
-                double Sn = 0;
-                for (int i = 0; i < 2 * n; ++i) Sn += S.lm_rn[i] * S.lm_rn[i];
-                if (Sn < S.lm_S) {
-                    for (int k = 0; k < 8; ++k) S.lm_h[k] = S.lm_hn[k];
-                    S.lm_S = Sn; S.lm_flag = 2;
-                    S.lm_lambda = S.lm_lambda - 1 < -16 ? -16 : S.lm_lambda - 1;
-                } else {
-                    S.lm_lambda = S.lm_lambda + 1 > 16 ? 16 : S.lm_lambda + 1;
+        WAVE_SYNC();
+        for (int it = 0; it < max_iters; ++it) {
+            {
+                const int a = tid >> 3, b = tid & 7;
+                double acc = 0;
+                for (int i = 0; i < 2 * n; ++i) acc += S.lm_J[(size_t)i * 8 + a] * S.lm_J[(size_t)i * 8 + b];
+                S.lm_A[a][b] = acc;
+                if (tid < 8) {
+                    double ag = 0;
+                    for (int i = 0; i < 2 * n; ++i) ag += S.lm_J[(size_t)i * 8 + tid] * S.lm_r[i];
+                    S.lm_g[tid] = ag;
                 }
             }
-            __syncthreads();
-            improved = S.lm_flag == 2;
-            __syncthreads();
+            WAVE_SYNC();
+            int improved = 0;
+            for (int tries = 0; tries < 16 && !improved; ++tries) {
+                {
+                    const int a = tid >> 3, b = tid & 7;
+                    const double lam = D_P10[S.lm_lambda + 16];
+                    double v = S.lm_A[a][b];
+                    if (a == b) v += lam * S.lm_A[a][a];
+                    S.lm_M[a][b] = v;
+                    if (tid < 8) S.lm_M[tid][8] = -S.lm_g[tid];
+                }
+                WAVE_SYNC();
+                const int solved = solve8_wave(S.lm_M, S.lm_d, tid);                 // (uniform)
+                if (!solved) {
+                    if (tid == 0) S.lm_lambda = S.lm_lambda + 1 > 16 ? 16 : S.lm_lambda + 1;
+                    WAVE_SYNC();
+                    continue;
+                }
+                if (tid < 8) S.lm_hn[tid] = S.lm_h[tid] + S.lm_d[tid];
+                WAVE_SYNC();
+                for (int i = tid; i < n; i += 64) lm_point(S.s2, S.d2, i, S.lm_hn, S.lm_rn, nullptr);
+                WAVE_SYNC();
+                if (tid == 0) {
+                    double Sn = 0;
+                    for (int i = 0; i < 2 * n; ++i) Sn += S.lm_rn[i] * S.lm_rn[i];
+                    if (Sn < S.lm_S) {
+                        for (int k = 0; k < 8; ++k) S.lm_h[k] = S.lm_hn[k];
+                        S.lm_S = Sn; S.lm_flag = 2;
+                        S.lm_lambda = S.lm_lambda - 1 < -16 ? -16 : S.lm_lambda - 1;
+                    } else {
+                        S.lm_flag = 1;
+                        S.lm_lambda = S.lm_lambda + 1 > 16 ? 16 : S.lm_lambda + 1;
+                    }
+                }
+                WAVE_SYNC();
+                improved = S.lm_flag == 2;
+                WAVE_SYNC();
+            }
+            if (!improved) break;
+            for (int i = tid; i < n; i += 64) lm_point(S.s2, S.d2, i, S.lm_h, S.lm_r, S.lm_J);
+            WAVE_SYNC();
         }
-        if (!improved) break;
-        for (int i = tid; i < n; i += POST_T) lm_point(S.s2, S.d2, i, S.lm_h, S.lm_r, S.lm_J);
-        __syncthreads();
+        if (tid < 8) S.best[tid] = S.lm_h[tid];
+        if (tid == 8) S.best[8] = 1.0;
     }
-    if (tid < 8) S.best[tid] = S.lm_h[tid];
-    if (tid == 8) S.best[8] = 1.0;
     __syncthreads();
 }
 
@@ -422,57 +461,120 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
 #else
 #define RT(acc_)
 #endif
+    constexpr int NDRAW = (RANSAC_WIN + 256) / POST_T;
+    unsigned pre[NDRAW];                               // the next round's slice of the stream, requested as soon as the chain walk knows where it starts: its
+    bool have_pre = false;                             // ~2 us of memory latency pass under the models and the replay instead of opening the round
     for (;;) {
         if (S.stop || S.iter >= S.niters) break;       // uniform: shared values, read after a barrier
         // (a) every window position: the sampling attempt that would start at that draw (getSubset's inner loops:
         //     draw until 4 distinct indices), its packed indices and the number of draws it consumes
-        for (int e = tid; e < RANSAC_WIN + 256; e += POST_T) {      // one coalesced pass over the stream, one modulo per draw
-            const int j = S.pos + e;
-            S.draw[e] = j < RNG_N ? (unsigned char)(rng_raw[j] % (unsigned)n) : (unsigned char)0;
+#pragma unroll
+        for (int ei = 0; ei < NDRAW; ++ei) {      // one coalesced pass over the stream, one modulo per draw
+            const int e = tid + ei * POST_T, j = S.pos + e;
+            const unsigned raw = have_pre ? pre[ei] : (j < RNG_N ? rng_raw[j] : 0u);
+            S.draw[e] = j < RNG_N ? (unsigned char)(raw % (unsigned)n) : (unsigned char)0;
         }
         __syncthreads();
-        for (int w = tid; w < RANSAC_WIN; w += POST_T) {
-            int j = S.pos + w, cnt = 0, idx[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int wi = 0; wi < RANSAC_WIN / POST_T; ++wi) {
+            const int w = tid + wi * POST_T;
+            // Eight draws of the window from LDS as three aligned words, parsed in registers without a branch (each draw against the up to three indices accepted before it);
+            // the draw-by-draw loop (one dependent LDS byte read per draw: 0.5 - 0.65 ms of the 2.3-ms kernel until round 5) only continues the rare attempts
+            // that repeat indices five times in eight draws, and serves the end of the stream.
+            int j = S.pos + w, cnt = 0;
             const int j0 = j;
-            while (cnt < 4 && j < RNG_N && j - j0 < 250) {
-                const int v = (int)S.draw[j++ - S.pos];
-                bool dup = false;
+            unsigned tuple = 0;
+            if (j0 + 8 <= RNG_N) {
+                const unsigned* dw = (const unsigned*)(S.draw + (w & ~3));
+                const unsigned long long lo = (unsigned long long)dw[0] | ((unsigned long long)dw[1] << 32), hi = dw[2];
+                const int sh = 8 * (w & 3);
+                const unsigned long long v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                unsigned i0 = 256, i1 = 256, i2 = 256;       // the indices accepted so far (256: none yet)
+                int len8 = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dup = dup || (q < cnt && idx[q] == v);
-                if (!dup) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (q == cnt) idx[q] = v;
-                    ++cnt;
+                for (int b = 0; b < 8; ++b) {
+                    const unsigned d = (unsigned)(v >> (8 * b)) & 255u;
+                    const bool fresh = d != i0 && d != i1 && d != i2 && cnt < 4;
+                    tuple |= fresh ? d << (8 * cnt) : 0u;
+                    i2 = (fresh && cnt == 2) ? d : i2; i1 = (fresh && cnt == 1) ? d : i1; i0 = (fresh && cnt == 0) ? d : i0;
+                    cnt += fresh;
+                    len8 = (cnt == 4 && len8 == 0) ? b + 1 : len8;
                 }
+                j = cnt == 4 ? j0 + len8 : j0 + 8;
+            }
+            if (cnt < 4) {
+                int idx[4] = {(int)(tuple & 255), (int)((tuple >> 8) & 255), (int)((tuple >> 16) & 255), (int)(tuple >> 24)};
+                while (cnt < 4 && j < RNG_N && j - j0 < 250) {
+                    const int v = (int)S.draw[j++ - S.pos];
+                    bool dup = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dup = dup || (q < cnt && idx[q] == v);
+                    if (!dup) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (q == cnt) idx[q] = v;
+                        ++cnt;
+                    }
+                }
+                tuple = (unsigned)idx[0] | ((unsigned)idx[1] << 8) | ((unsigned)idx[2] << 16) | ((unsigned)idx[3] << 24);
             }
             S.len[w] = cnt == 4 ? (unsigned char)(j - j0) : 0;
-            S.tuple[w] = (unsigned)idx[0] | ((unsigned)idx[1] << 8) | ((unsigned)idx[2] << 16) | ((unsigned)idx[3] << 24);
+            S.tuple[w] = tuple;
         }
         __syncthreads();
         RT(tA)
-        if (tid < 64) {                               // (b) hop chain: attempt k starts where attempt k-1 stopped drawing
-            // Sequential by nature, but almost every attempt consumes exactly 4 draws (no repeated index): one wave guesses that the
-            // next 64 attempts do, checks all of them at once, accepts the run up to the first one that does not, and restarts behind it.
-            int p = 0, k = 0;
-            for (;;) {
-                const int room = POST_T - k;
-                if (room <= 0 || p >= RANSAC_WIN) break;
-                const int q = p + 4 * tid;
-                const int len = (tid < room && q < RANSAC_WIN) ? (int)S.len[q] : 0;
-                const unsigned long long bad = __ballot(len != 4);
-                const int f = bad ? __ffsll((long long)bad) - 1 : 64;       // lanes below f start where the guess says
-                if (tid < f) S.start[k + tid] = q;
-                if (f == 64) { k += 64; p += 256; continue; }
-                const int lf = __shfl(len, f), qf = __shfl(q, f);
-                if (lf <= 0) { k += f; p = qf; break; }                  // stream exhausted / beyond the window / no room: stop in front of it
-                if (tid == 0) S.start[k + f] = qf;
-                k += f + 1; p = qf + lf;
+        // (b) the attempt chain: attempt k starts where attempt k-1 stopped drawing, s_0 = 0, s_k+1 = next(s_k) with next(w) = w + len[w].  A position without
+        //     an attempt (len 0: stream exhausted) or beyond the window is absorbing.  Until round 5 one wave walked the chain with a guess-and-check per 64
+        //     attempts (0.56 - 0.63 ms of the kernel at ~5.3 draws per attempt); now pointer doubling: next^4, next^16 and next^64 for every window position,
+        //     three passes of four dependent reads, and thread k reaches s_k in at most twelve hops along the base-4 digits of k.
+        {
+            auto nx0 = [&](int w) -> int { if (w >= RANSAC_WIN) return w; const int l = (int)S.len[w]; return w + l; };      // (len 0: w itself)
+            constexpr int NPOS = RANSAC_WIN / POST_T;          // window positions per thread: their hop chains are independent and interleave (the loops are unrolled)
+            int xs[NPOS];
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i) xs[i] = tid + i * POST_T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) xs[i] = nx0(xs[i]);
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i) S.jump[0][tid + i * POST_T] = (unsigned short)xs[i];
+            __syncthreads();
+#pragma unroll
+            for (int lv = 1; lv < 3; ++lv) {
+                const unsigned short* P = S.jump[lv - 1];
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) xs[i] = tid + i * POST_T;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < NPOS; ++i) xs[i] = xs[i] < RANSAC_WIN ? (int)P[xs[i]] : xs[i];
+#pragma unroll
+                for (int i = 0; i < NPOS; ++i) S.jump[lv][tid + i * POST_T] = (unsigned short)xs[i];
+                __syncthreads();
             }
-            if (tid == 0) { S.natt = k; S.newpos = S.pos + p; }
+            int x = 0;
+            for (int r = 0; r < (tid >> 6); ++r) x = x < RANSAC_WIN ? (int)S.jump[2][x] : x;
+            for (int r = 0; r < ((tid >> 4) & 3); ++r) x = x < RANSAC_WIN ? (int)S.jump[1][x] : x;
+            for (int r = 0; r < ((tid >> 2) & 3); ++r) x = x < RANSAC_WIN ? (int)S.jump[0][x] : x;
+            for (int r = 0; r < (tid & 3); ++r) x = nx0(x);
+            const int lenx = x < RANSAC_WIN ? (int)S.len[x] : 0;
+            const bool live = lenx > 0;                  // attempt tid exists; the chain is monotone: live for tid < natt, and every dead thread sits on the same position
+            S.start[tid] = x;
+            const int nl = __popcll(__ballot(live));
+            if ((tid & 63) == 0) S.wlive[tid >> 6] = nl;
+            if (!live) S.newpos = S.pos + x;             // (the same value from every dead thread)
+            else if (tid == POST_T - 1) S.newpos = S.pos + x + lenx;
         }
         __syncthreads();
         RT(tB)
-        if (tid < S.natt) {                           // (c) degeneracy test, 4-point model and its support, in parallel
+        const int natt = S.wlive[0] + S.wlive[1] + S.wlive[2] + S.wlive[3];      // (uniform)
+        {
+            const int np = S.newpos;
+#pragma unroll
+            for (int ei = 0; ei < NDRAW; ++ei) { const int j = np + tid + ei * POST_T; pre[ei] = j < RNG_N ? rng_raw[j] : 0u; }
+            have_pre = true;
+        }
+        if (tid < natt) {                           // (c) degeneracy test, 4-point model and its support, in parallel
             const unsigned tp = S.tuple[S.start[tid]];
             const int idx[4] = {(int)(tp & 255), (int)((tp >> 8) & 255), (int)((tp >> 16) & 255), (int)(tp >> 24)};
             unsigned char code = 255;
@@ -493,61 +595,55 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
         }
         __syncthreads();
         RT(tC)
-        if (tid == 0) {                               // (d) replay the attempts in order = the sequential RANSAC loop
+        if (tid < 64) {                               // (d) replay the attempts in order = the sequential RANSAC loop
+            // One wave, 64 attempts at a time.  Between two EVENTS the loop only counts: iter += the attempts that are not degenerate subsets, fail_run = the run of
+            // degenerate subsets at the end.  The events, each found with a ballot: (A) the first attempt whose inlier count beats the running best (new best model,
+            // new iteration bound); (B) the attempt with which iter reaches the bound (nothing behind it is looked at); (C) the 1000th consecutive degenerate subset
+            // (only a run that starts at the cursor can get there).  The segment up to and including the first event is folded in one step, then the masks are
+            // rebuilt behind it.  Until round 5 one lane walked the codes (16 at a time where nothing could happen): 0.22 - 0.29 ms of the kernel.
             int iter = S.iter, fail_run = S.fail_run, niters = S.niters, max_good = S.max_good, stop = 0;
-            const int natt = S.natt;
             if (natt == 0) stop = 1;                  // precomputed stream exhausted
-            for (int c16 = 0; c16 * 16 < natt && !stop && iter < niters; ++c16) {
-                const uint4 pk = *(const uint4*)&S.code[c16 * 16];
-                const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
-                {   // 16 attempts at once when none of them can change the state beyond counters: no new best (every inlier count, i.e. every
-                    // byte below 128, is <= the running best), the iteration bound is not reached inside the chunk, no 1000-failure stop
-                    unsigned m255[4], improv = 0; int n255 = 0;
+            for (int base = 0; base < natt && !stop && iter < niters; base += 64) {
+                const int k = base + tid;
+                const int code = k < natt ? (int)S.code[k] : 255;
+                const int last = natt - 1 - base < 63 ? natt - 1 - base : 63;       // last lane with an attempt
+                int cur = 0;
+                while (cur <= last && !stop && iter < niters) {
+                    const bool here = tid >= cur && tid <= last;
                     const int thr = max_good > 3 ? max_good : 3;
-                    const unsigned add = (unsigned)(127 - thr) * 0x01010101u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        m255[j] = ((wds[j] & 0x7F7F7F7Fu) + 0x01010101u) & wds[j] & 0x80808080u;       // bit 7 of a byte: the byte is 255
-                        n255 += __popc(m255[j]);
-                        improv |= ((wds[j] & 0x7F7F7F7Fu) + add) & 0x80808080u & ~wds[j];
+                    const unsigned long long vmask = __ballot(here && code != 255);
+                    const unsigned long long imask = __ballot(here && code < 254 && code > thr);
+                    const int fv = vmask ? __ffsll((long long)vmask) - 1 : last + 1;                     // first attempt that counts as an iteration
+                    const int need = 1000 - fail_run;
+                    const int fc = fv - cur >= need ? cur + need - 1 : 64;                               // (C)
+                    const int fa = imask ? __ffsll((long long)imask) - 1 : 64;                           // (A)
+                    const int R = niters - iter;                                                         // (B): the R-th counting attempt
+                    const int pc = __popcll(vmask & ((2ull << tid) - 1ull));
+                    const unsigned long long bmask = __ballot(here && code != 255 && pc == R);
+                    const int fb = bmask ? __ffsll((long long)bmask) - 1 : 64;
+                    int E = fc < fa ? fc : fa; E = fb < E ? fb : E;
+                    const bool event = E < 64;
+                    if (!event) E = last;
+                    const unsigned long long seg = vmask & ((2ull << E) - 1ull);                         // counting attempts of [cur, E]
+                    const int nv = __popcll(seg);
+                    iter += nv;
+                    fail_run = nv ? E - (63 - __clzll((long long)seg)) : fail_run + (E - cur + 1);
+                    if (event && E == fc) {                                                              // (in front of every counting attempt: nv == 0)
+                        if (iter == 0) max_good = -1;
+                        stop = 1;
+                    } else if (event && E == fa) {
+                        const int kb = base + E, cb = __shfl(code, E);
+                        if (tid < 9) S.best[tid] = S.cand[kb][tid];
+                        max_good = cb;
+                        niters = ransac_update_iters(0.995, (double)(n - cb) / n, 4, niters);
                     }
-                    const int nvalid = 16 - n255;
-                    if (c16 * 16 + 16 <= natt && thr <= 127 && !improv && iter + nvalid < niters && fail_run + 16 < 1000) {
-                        iter += nvalid;
-                        if (nvalid == 0) fail_run += 16;
-                        else {
-                            int last = 0;                                 // index of the last attempt of the chunk that is not a degenerate subset
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const unsigned nm = ~m255[j] & 0x80808080u;
-                                if (nm) last = j * 4 + ((31 - __clz((int)nm)) >> 3);
-                            }
-                            fail_run = 15 - last;
-                        }
-                        continue;
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const int k = c16 * 16 + b;
-                    const int code = (int)((wds[b >> 2] >> (8 * (b & 3))) & 255u);
-                    if (k < natt && !stop && iter < niters) {
-                        if (code == 255) {            // getSubset keeps drawing (at most 1000 attempts per iteration)
-                            if (++fail_run >= 1000) { if (iter == 0) max_good = -1; stop = 1; }
-                        } else {
-                            fail_run = 0;
-                            if (code != 254 && code > (max_good > 3 ? max_good : 3)) {
-                                for (int j = 0; j < 9; ++j) S.best[j] = S.cand[k][j];
-                                max_good = code;
-                                niters = ransac_update_iters(0.995, (double)(n - code) / n, 4, niters);
-                            }
-                            ++iter;
-                        }
-                    }
+                    cur = E + 1;
                 }
             }
-            S.niters = niters; S.max_good = max_good; if (stop) S.stop = 1;
-            S.iter = iter; S.fail_run = fail_run; S.pos = S.newpos;
+            if (tid == 0) {
+                S.niters = niters; S.max_good = max_good; if (stop) S.stop = 1;
+                S.iter = iter; S.fail_run = fail_run; S.pos = S.newpos;
+            }
         }
         __syncthreads();
         RT(tD)
@@ -558,6 +654,7 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
     __syncthreads();
 #ifdef EAGLE_DEBUG_RANSAC
     if (tid == 0) printf("ransac: rounds %d iter %d  parse %.1f us  hop %.1f us  models %.1f us  replay %.1f us (100 MHz ticks)\n", rounds_, S.iter, tA * 0.01, tB * 0.01, tC * 0.01, tD * 0.01);
+    long long tE = 0, tF = 0; t0_ = wall_clock64();
 #endif
     if (S.max_good <= 0) return;                      // S.ok == 0
     for (int i = tid; i < n; i += POST_T) S.mask[i] = reproj_err1(S.src, S.dst, i, S.best) <= t2;
@@ -579,8 +676,13 @@ __device__ void find_homography_block(HomoShared& S, const unsigned* __restrict_
         }
     }
     __syncthreads();
+    RT(tE)
     if (S.ni > 0 && lm_iters > 0) lm_refine_block(S, S.ni, lm_iters);
     __syncthreads();
+    RT(tF)
+#ifdef EAGLE_DEBUG_RANSAC
+    if (tid == 0) printf("        inlier fit (mask + DLT + Jacobi) %.1f us  LM polish %.1f us  (%d inliers)\n", tE * 0.01, tF * 0.01, S.ni);
+#endif
 }
 
 // ---- cv2.fitLine(DIST_L2) closed form and the 2x2 intersection -------------------------------------------------

@@ -625,7 +625,9 @@ struct YoloBuilder {
     }
 };
 
-static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3], int nc)
+// mixed (EAGLE_DET_PREC_MIXED; VERDICT r5 task 7): the trunk in the split family, the LAST C2f of every level (model.15 / 18 / 21), the two stride-2 convolutions between them
+// (model.16 / 19) and Detect (model.22) in the exact fp32 family; the seam is an exact conversion of the three concat buffers (split_to_f32_launch).
+static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3], int nc, bool mixed = false)
 {
     YoloBuilder Y{B};
     const YoloDims d = yolo_dims(variant);
@@ -663,22 +665,44 @@ static void build_yolo(Builder& B, const TView& x_in, int variant, DetLevel lv[3
         B.other([p5, u](hipStream_t s) { upsample2_launch(p5, u, s); }, "upsample2", Builder::vbytes(p5) + Builder::vbytes(u));
         Y.c2f(cat12, 12, c4, d.n[0], false, &h12);
     }
-    TView h15;
+    TView h15, h18, h21;
     {
         TView u = cat15.slice(0, c4);
         B.other([h12, u](hipStream_t s) { upsample2_launch(h12, u, s); }, "upsample2", Builder::vbytes(h12) + Builder::vbytes(u));
+    }
+    if (!mixed) {
         h15 = Y.c2f(cat15, 15, c3, d.n[0], false);
+        {
+            TView o = cat18.slice(0, c3);
+            Y.cv(h15, "model.16", 2, nullptr, &o);
+        }
+        h18 = Y.c2f(cat18, 18, c4, d.n[0], false);
+        {
+            TView o = cat21.slice(0, c4);
+            Y.cv(h18, "model.19", 2, nullptr, &o);
+        }
+        h21 = Y.c2f(cat21, 21, c5, d.n[0], false);
+    } else {
+        B.prec = EAGLE_PREC_F32;                           // every tensor allocated and every convolution built from here on: the exact family
+        auto to_f32 = [&B](const TView& x, const TView& y) {
+            B.other([x, y](hipStream_t s) { split_to_f32_launch(x, y, s); }, "split_to_f32", Builder::vbytes(x) + Builder::vbytes(y));
+        };
+        TView cat15f = B.act(h3, w3, c4 + c3), cat18f = B.act(h4, w4, c3 + c4), cat21f = B.act(h5, w5, c4 + c5);
+        to_f32(cat15, cat15f);
+        h15 = Y.c2f(cat15f, 15, c3, d.n[0], false);
+        {
+            TView o = cat18f.slice(0, c3);
+            Y.cv(h15, "model.16", 2, nullptr, &o);
+            to_f32(h12, cat18f.slice(c3, c4));
+        }
+        h18 = Y.c2f(cat18f, 18, c4, d.n[0], false);
+        {
+            TView o = cat21f.slice(0, c4);
+            Y.cv(h18, "model.19", 2, nullptr, &o);
+            to_f32(p5, cat21f.slice(c4, c5));
+        }
+        h21 = Y.c2f(cat21f, 21, c5, d.n[0], false);
     }
-    {
-        TView o = cat18.slice(0, c3);
-        Y.cv(h15, "model.16", 2, nullptr, &o);
-    }
-    TView h18 = Y.c2f(cat18, 18, c4, d.n[0], false);
-    {
-        TView o = cat21.slice(0, c4);
-        Y.cv(h18, "model.19", 2, nullptr, &o);
-    }
-    TView h21 = Y.c2f(cat21, 21, c5, d.n[0], false);
     const TView feats[3] = {h15, h18, h21};
     const float strides[3] = {8.f, 16.f, 32.f};
     int a0 = 0;
@@ -1196,7 +1220,8 @@ static void finalize(EagleHandle* h)
     const EagleConfig& c = h->cfg;
     const int B = c.batch;
     h->prec = c.precision;
-    h->det_prec = c.det_precision ? c.det_precision - 1 : c.precision;
+    const bool det_mixed = c.det_precision == EAGLE_DET_PREC_MIXED;
+    h->det_prec = det_mixed ? EAGLE_PREC_F32S : c.det_precision ? c.det_precision - 1 : c.precision;
     h->hr.reset(new Net); h->yo.reset(new Net); h->misc.reset(new Net);
     const int cin_pad = h->prec == EAGLE_PREC_F32 ? 4 : 8, det_cin_pad = h->det_prec == EAGLE_PREC_F32 ? 4 : 8;
     h->lb = letterbox_geometry(c.frame_h, c.frame_w, c.det_imgsz, c.letterbox);
@@ -1207,7 +1232,7 @@ static void finalize(EagleHandle* h)
     h->kp_in = Bh.act(540, 960, cin_pad);
     h->det_in = By.act(h->lb.out_h, h->lb.out_w, det_cin_pad);
     h->logits = build_hrnet(Bh, h->kp_in);
-    build_yolo(By, h->det_in, c.det_variant, h->levels, 5);
+    build_yolo(By, h->det_in, c.det_variant, h->levels, 5, det_mixed);
     if (h->weights.count(std::string(RP) + "conv1.conv.weight")) {          // appearance embeddings for the tracker: only when the caller loaded an OSNet
         h->reid.reset(new Net);
         Builder Br{h, h->reid.get(), EAGLE_PREC_F32, 1e-5, REID_NB};
@@ -1316,7 +1341,7 @@ int eagle_create(const EagleConfig* cfg, EagleHandle** out)
     if (cfg->det_variant < 0 || cfg->det_variant > 4) fail(EAGLE_E_INVALID, "bad detector variant");
     if (cfg->letterbox != EAGLE_LETTERBOX_RECT && cfg->letterbox != EAGLE_LETTERBOX_SQUARE) fail(EAGLE_E_INVALID, "letterbox: 0 (rect, auto=True) or 1 (square, auto=False)");
     if (cfg->det_imgsz < 32 || cfg->det_imgsz % 32) fail(EAGLE_E_INVALID, "det_imgsz must be a positive multiple of 32 (the detector's largest stride)");
-    if (cfg->det_precision < EAGLE_DET_PREC_AUTO || cfg->det_precision > EAGLE_PREC_F32S + 1) fail(EAGLE_E_INVALID, "bad detector precision");
+    if (cfg->det_precision < EAGLE_DET_PREC_AUTO || cfg->det_precision > EAGLE_DET_PREC_MIXED) fail(EAGLE_E_INVALID, "bad detector precision");
     if (cfg->use_graph < EAGLE_AUTO || cfg->use_graph > 2 || cfg->multi_stream < EAGLE_AUTO || cfg->multi_stream > 1) fail(EAGLE_E_INVALID, "use_graph: -1 (auto), 0, 1 or 2; multi_stream: -1 (auto), 0 or 1");
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));

@@ -17,6 +17,7 @@ DET_VARIANTS = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
 AUTO, SMALL_BATCH, MULTI_STREAM_BATCH = -1, 8, 16                                              # include/eagle.h EAGLE_AUTO / EAGLE_SMALL_BATCH (use_graph: 0 off, 1 every step, 2 inside calls of >= 3 steps; multi_stream)
 LETTERBOX = {"rect": 0, "square": 1}                                    # include/eagle.h EAGLE_LETTERBOX_*: ultralytics LetterBox auto=True (the .pt predictor) / auto=False (the exported ONNX detector of cm.py:54-55)
 DET_PREC_AUTO = -1                                                     # include/eagle.h EAGLE_DET_PREC_AUTO
+DET_PREC_MIXED = 4                                                     # include/eagle.h EAGLE_DET_PREC_MIXED (split trunk, exact last C2f per level + Detect)
 
 
 class EagleError(RuntimeError):

@@ -47,6 +47,8 @@ extern "C" {
 #define EAGLE_SMALL_BATCH 8      /* steps of at most this many frames replay their network phase as a hipGraph unless the caller says otherwise */
 #define EAGLE_MULTI_STREAM_BATCH 16 /* ... and steps of at most this many run HRNet's branches on their own streams (measured: +13 % at 12 and 16 frames, +2 % at 25, nothing at 50) */
 #define EAGLE_DET_PREC_AUTO (-1) /* EagleConfig::det_precision: chosen from `precision` by eagle_create */
+#define EAGLE_DET_PREC_MIXED 4   /* EagleConfig::det_precision: the detector's trunk in EAGLE_PREC_F32S; the last C2f of every level (model.15 / 18 / 21), model.16 / 19 and
+                                    Detect in EAGLE_PREC_F32.  Measured and NOT the default: it does not keep the exact family's detection ids */
 
 #define EAGLE_LETTERBOX_RECT 0
 #define EAGLE_LETTERBOX_SQUARE 1

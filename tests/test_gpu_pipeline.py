@@ -519,8 +519,10 @@ def test_f32s_family_equals_fp32_oracle_cfg3(cfg3_case):
     assert sum(t["conf_tie"] for t in tot) <= 0.04 * sum(t["dets"] for t in tot), tot
 
 
-def test_f32s_ids_identical_with_a_sparse_detector(state_dicts):
-    """The id contract (detection index in descending-confidence order, cm.py:598-616) with a realistic number of detections: the class
+@pytest.mark.parametrize("det", ["f32s", "mixed"])
+def test_f32s_ids_identical_with_a_sparse_detector(state_dicts, det):
+    """(det = "mixed", round 6: EAGLE_DET_PREC_MIXED — split trunk, exact last C2f per level + Detect, seamed by split_to_f32 — under the same contract.)
+    The id contract (detection index in descending-confidence order, cm.py:598-616) with a realistic number of detections: the class
     biases of the synthetic detector lowered until a frame keeps a few dozen boxes, confidences then lie ~1e-2 apart and every id, class,
     integer box and pitch integer must equal the fp32 oracle's with NO admitted exception."""
     from eagle_amd import synth
@@ -532,14 +534,14 @@ def test_f32s_ids_identical_with_a_sparse_detector(state_dicts):
     for l in range(3):
         ys2[f"model.22.cv3.{l}.2.bias"] = (ys[f"model.22.cv3.{l}.2.bias"] - np.float32(1.25)).astype(np.float32)
     frames = np.stack([synth.frame(*g["design"]), synth.frame(0, 9), synth.frame(2, 5)])
-    cm = CoordinateModel(precision="f32s", detector_precision="f32s", batch=3, hrnet_state_dict=hs2, detector_state_dict=ys2)
+    cm = CoordinateModel(precision="f32s", detector_precision=det, batch=3, hrnet_state_dict=hs2, detector_state_dict=ys2)
     recs = cm.process_records(frames)
     cm.handle.close()
     ora = pipeline.OracleModel(hs2, ys2, backend="c")
     tot = []
     for i, f in enumerate(frames):
         oref, aux = ora.step(f, i)
-        tot.append(_f32s_record_parity(recs[i], oref, aux, f"f32s sparse detector frame {i}", (720, 1280), score_tol=3e-5))
+        tot.append(_f32s_record_parity(recs[i], oref, aux, f"f32s sparse detector ({det}) frame {i}", (720, 1280), score_tol=3e-5))
     print("f32s parity (sparse detector):", tot)
     assert all(3 <= t["dets"] <= 120 for t in tot), [t["dets"] for t in tot]
     assert sum(t["hm_tie"] + t["near_int_box"] + t["conf_tie"] for t in tot) == 0, tot

@@ -504,9 +504,10 @@ void conv_launch(int precision, const ConvLaunch& L, hipStream_t s)
         if ((size_t)a.N * a.H * a.W * a.xcs * 2 >= lim || (size_t)a.N * a.Ho * a.Wo * std::max(std::max(a.ycs, a.r1 ? a.r1cs : 0), a.r2 ? a.r2cs : 0) * 2 >= lim)
             fail(EAGLE_E_INVALID, "fp16 conv: a tensor of %d frames reaches 2 GiB; use a smaller device batch", a.N);
         const int nres = (a.r1 ? 1 : 0) + (a.r2 ? 1 : 0);
-        const ConvKernel fn = conv_ad_m32(c) ? (conv_ad_tw(c) == 64 ? conv_ad_split32_kernel_w64(conv_ad_wide(c), nres) : conv_ad_split32_kernel(conv_ad_wide(c), nres)) : (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 19) ? conv_ad_split_kernel48ring(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
-        ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         const int items = a.tiles_x * a.tiles_y * a.N * a.gy;
+        const bool deep = items <= 256;                     // at most one workgroup per CU: the deep weight ring (conv_ad_split32.hip)
+        const ConvKernel fn = conv_ad_m32(c) ? (conv_ad_tw(c) == 64 ? conv_ad_split32_kernel_w64(conv_ad_wide(c), nres, deep) : conv_ad_split32_kernel(conv_ad_wide(c), nres, deep)) : (split && conv_ad_s2t(c)) ? conv_ad_split_kernel_s2t(c.variant == 14, nres) : (split && c.stride == 2) ? conv_ad_split_kernel_s2(conv_ad_wide(c), nres) : (split && c.variant == 13) ? conv_ad_split_kernel48sb(nres) : (split && c.variant == 19) ? conv_ad_split_kernel48ring(nres) : (split && c.variant == 12) ? conv_ad_split_kernel48(nres) : split ? conv_ad_split_kernel(conv_ad_wide(c), nres) : c.stride == 2 ? conv_ad_kernel_s2(conv_ad_wide(c), nres) : conv_ad_kernel_s1(conv_ad_wide(c), nres);
+        ensure_max_dynamic_lds((const void*)fn, 160 * 1024);
         // workgroups per launch: one per item (the hardware hands a queued workgroup to whichever CU frees a slot: dynamic balance) rather than 512
         // resident ones walking static item ranges — same box, alternating: 774.4 / 774.5 -> 779.0 / 780.7 frames/s, 96->96 209.9 -> 204.4 us,
         // 192->192 180.3 -> 177.2 (768 workgroups: 707 frames/s — 1.5 rounds of uneven ranges).  EAGLE_CONV_AD_SLOTS=512 restores the persistent form.

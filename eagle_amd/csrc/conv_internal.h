@@ -50,8 +50,8 @@ const Inst* conv_inst_split0(int* n); const Inst* conv_inst_split1(int* n); cons
 ConvKernel conv_ad_kernel_s1(bool wide, int n_res);
 ConvKernel conv_ad_kernel_s2(bool wide, int n_res);
 ConvKernel conv_ad_split_kernel(bool wide, int n_res);      // EAGLE_PREC_F32S form (conv_ad_split.inc), stride 1
-ConvKernel conv_ad_split32_kernel_w64(bool wide, int n_res); // ... with the wave's two pixel blocks side by side: BN = 192, tile 2 x 64 (variant 23) / BN = 96, tile 4 x 64 (variant 24)
-ConvKernel conv_ad_split32_kernel(bool wide, int n_res);    // the 32x32x16 form (conv_ad_split32.inc): BN = 192, tile 4 x 32 (variant 21) / BN = 96, tile 8 x 32 (variant 22)
+ConvKernel conv_ad_split32_kernel_w64(bool wide, int n_res, bool deep); // ... with the wave's two pixel blocks side by side: BN = 192, tile 2 x 64 (variant 23) / BN = 96, tile 4 x 64 (variant 24)
+ConvKernel conv_ad_split32_kernel(bool wide, int n_res, bool deep);    // the 32x32x16 form (conv_ad_split32.inc): BN = 192, tile 4 x 32 (variant 21) / BN = 96, tile 8 x 32 (variant 22)
 ConvKernel conv_ad_split_kernel48(int n_res);               // the same for Cout = 48 (K split over wave pairs; variant 12)
 ConvKernel conv_ad_split_kernel_s2(bool wide, int n_res);    // stride 2 (variants 10 / 11 of the split family)
 ConvKernel conv_ad_split_kernel_s2t(bool wide, int n_res);   // TRUE stride 2 on a column-plane halo, single halo buffer: BN = 192 (variant 14) / BN = 96 with the K split (variant 15)

@@ -16,6 +16,9 @@
 #   bneck_ab         whole-pipeline A/B EAGLE_BNECK_FUSED=0/1, three alternating pairs
 #   bneck_ds_ab      whole-pipeline A/B EAGLE_BNECK_DS=0/1 (block 0's downsample branch inside the fused launch), three alternating pairs
 #   bneck_ds         operator-level and pipeline probes of the downsample-fused launch (tools/probes/bneck_ds_probe.py, bneck_ds_pipeline_probe.py)
+#   env_ab:<VAR=v>   whole-pipeline A/B of one environment knob (unset / set), three alternating pairs, no extras          -> env_ab.log
+#   lat_ab:<VAR=v>   one-, two- and four-frame call latency with the knob unset / set, two alternating pairs (tools/probes/latency_env_ab.sh)
+#   b1trace          rocprofv3 --kernel-trace of 40 one-frame calls + tools/probes/latency_b1_trace.py parse                -> b1_critical_path.txt
 #   cpu_sweep        cpu_baseline thread sweep (16 32 64 128)
 tag=${1:-x}; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
@@ -47,6 +50,13 @@ for step in "$@"; do
              EAGLE_BNECK_DS=$f timeout 600 python bench.py --no-extras --no-cpu-baseline --latency-calls 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'frames/s', d['ms_per_step'], 'ms/step; conv family', d['roofline']['conv_ms_per_step'], 'ms, frac', d['roofline']['frac'])" >> $L 2>&1
            done; done; cat $L ;;
     bneck_ds) timeout 600 python tools/probes/bneck_ds_probe.py > $O/bneck_ds_probe.log 2>&1; timeout 600 python tools/probes/bneck_ds_pipeline_probe.py > $O/bneck_ds_pipeline_probe.log 2>&1; tail -4 $O/bneck_ds_probe.log $O/bneck_ds_pipeline_probe.log ;;
+    env_ab:*) L=$O/env_ab.log; kv=${step#env_ab:}
+           for rep in 1 2 3; do for f in 0 1; do if [ $f = 0 ]; then echo "unset rep $rep" >> $L; pre=""; else echo "$kv rep $rep" >> $L; pre="$kv"; fi
+             env $pre timeout 600 python bench.py --no-extras --no-cpu-baseline --latency-calls 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'frames/s', d['ms_per_step'], 'ms/step; conv family', d['roofline']['conv_ms_per_step'], 'ms, frac', d['roofline']['frac'])" >> $L 2>&1
+           done; done; cat $L ;;
+    lat_ab:*) bash tools/probes/latency_env_ab.sh $tag ${step#lat_ab:} ;;
+    b1trace) (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $O/b1trace -- python3 $R/tools/probes/latency_b1_trace.py run > $O/b1trace.log 2>&1)
+             python3 tools/probes/latency_b1_trace.py parse $O/b1trace > $O/b1_critical_path.txt 2>&1; find $O/b1trace -name "*kernel_trace.csv" -delete; head -30 $O/b1_critical_path.txt ;;
     cpu_sweep) for t in 16 32 64 128; do echo "threads $t" >> $O/cpu_baseline_thread_sweep.txt; timeout 600 python bench.py --cpu-baseline-only --cpu-threads $t --cpu-frames 40 2>/dev/null | tail -1 >> $O/cpu_baseline_thread_sweep.txt; done; cat $O/cpu_baseline_thread_sweep.txt ;;
     *) echo "unknown step $step" ;;
   esac

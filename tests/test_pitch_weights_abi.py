@@ -101,6 +101,10 @@ def test_default_config_semantics_and_new_fields():
     assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32S)).det_precision == lib.PREC_F32 + 1
     assert lib.resolve_config(lib.default_config(precision=lib.PREC_F16, det_precision=lib.PREC_F32S + 1)).det_precision == lib.PREC_F32S + 1
     assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32S, det_precision=0)).det_precision == 0
+    # round 6: the mixed detector (split trunk, exact last C2f per level + Detect) is an explicit choice, kept as given, and the header's constant is lib.py's
+    assert lib.resolve_config(lib.default_config(precision=lib.PREC_F32S, det_precision=lib.DET_PREC_MIXED)).det_precision == lib.DET_PREC_MIXED
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "eagle.h")).read()
+    assert re.search(r"#define\s+EAGLE_DET_PREC_MIXED\s+%d\b" % lib.DET_PREC_MIXED, hdr)
     # small-batch mode (round 5): use_graph / multi_stream default to "auto" and resolve from the batch
     assert (c.use_graph, c.multi_stream) == (lib.AUTO, lib.AUTO)
     os.environ.pop("EAGLE_MULTI_STREAM", None)

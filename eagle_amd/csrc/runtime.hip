@@ -485,7 +485,14 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
         B.fork_join(Op::JOIN, nb - 1);
         const int n_out = (last_single && m == n_modules - 1) ? 1 : nb;
         std::vector<TView> out;
+        // (round 6) The fuse outputs are independent of each other: output i — its chain of stride-2 convolutions from the higher-resolution branches, its 1 x 1
+        // convolutions of the lower ones, its fuse_sum — is emitted for stream i, so that with branch streams on (small batches) the module's 19 fuse launches are
+        // four parallel chains of at most 6 instead of one serial chain behind the join: 0.85 ms of a one-frame call (7.5 -> 6.66 ms, profiles/r06ad_*).  The inputs
+        // xs[] are only read; everything a chain allocates and releases stays in its own stream's pool.  Same launches, same arithmetic.  (Measured and not kept: also
+        // moving the launches that need only ONE branch's output in front of the join, behind that branch — nothing; the branches enqueued longest-first — nothing.)
+        if (n_out > 1) B.fork_join(Op::FORK, n_out - 1);
         for (int i = 0; i < n_out; ++i) {
+            B.set_stream(n_out > 1 ? i : 0);
             TView y; bool have_y = false;
             for (int j = 0; j < i; ++j) {
                 TView t = xs[j];
@@ -524,6 +531,8 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
             }
             out.push_back(y);
         }
+        B.set_stream(0);
+        if (n_out > 1) B.fork_join(Op::JOIN, n_out - 1);
         // inputs of this module's fuse are dead now (xs[0] may be aliased by out[0] only when nb == 1, never here)
         for (int b = 0; b < nb; ++b) B.release(xs[b]);
         xs = out;

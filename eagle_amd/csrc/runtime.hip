@@ -468,18 +468,20 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
     for (int m = 0; m < n_modules; ++m) {
         const std::string q = std::string(HRP) + "stage" + std::to_string(stage_idx) + "." + std::to_string(m) + ".";
         B.fork_join(Op::FORK, nb - 1);          // the branches of a module are independent until the fuse
-        for (int b = 0; b < nb; ++b) {
+        // emission order (= host launch order, and node order of a captured graph): block k of every branch before block k + 1 of any, the widest branch first —
+        // a branch's first launch is then not queued behind the whole chains of the branches before it: one-frame call 6.74 -> 6.63 ms, four frames 8.62 -> 8.46
+        // (profiles/r06ag_*; EAGLE_HR_INTERLEAVE=0: branch after branch)
+        const bool interleave = !(getenv("EAGLE_HR_INTERLEAVE") && atoi(getenv("EAGLE_HR_INTERLEAVE")) == 0);
+        for (int step = 0; step < 4 * nb; ++step) {
+            const int k = interleave ? step / nb : step % 4, b = interleave ? nb - 1 - step % nb : step / 4;
             B.set_stream(b);
             TView x = xs[b];
-            for (int k = 0; k < 4; ++k) {
-                const std::string r = q + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
-                TView o = B.conv(x, r + "conv1", r + "bn1", 1, 0, nullptr, nullptr, R);
-                TView y = B.conv(o, r + "conv2", r + "bn2", 1, 0, &x, nullptr, R);
-                B.release(o);
-                B.release(x);
-                x = y;
-            }
-            xs[b] = x;
+            const std::string r = q + "branches." + std::to_string(b) + "." + std::to_string(k) + ".";
+            TView o = B.conv(x, r + "conv1", r + "bn1", 1, 0, nullptr, nullptr, R);
+            TView y = B.conv(o, r + "conv2", r + "bn2", 1, 0, &x, nullptr, R);
+            B.release(o);
+            B.release(x);
+            xs[b] = y;
         }
         B.set_stream(0);
         B.fork_join(Op::JOIN, nb - 1);
@@ -489,7 +491,7 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
         // convolutions of the lower ones, its fuse_sum — is emitted for stream i, so that with branch streams on (small batches) the module's 19 fuse launches are
         // four parallel chains of at most 6 instead of one serial chain behind the join: 0.85 ms of a one-frame call (7.5 -> 6.66 ms, profiles/r06ad_*).  The inputs
         // xs[] are only read; everything a chain allocates and releases stays in its own stream's pool.  Same launches, same arithmetic.  (Measured and not kept: also
-        // moving the launches that need only ONE branch's output in front of the join, behind that branch — nothing; the branches enqueued longest-first — nothing.)
+        // moving the launches that need only ONE branch's output in front of the join, behind that branch — nothing, twice: profiles/r06ai_*.)
         if (n_out > 1) B.fork_join(Op::FORK, n_out - 1);
         for (int i = 0; i < n_out; ++i) {
             B.set_stream(n_out > 1 ? i : 0);
@@ -572,9 +574,13 @@ static TView build_hrnet(Builder& B, const TView& x_in)
         B.release(x);
         x = y;
     }
-    std::vector<TView> ys;
-    ys.push_back(B.conv(x, P + "transition1.0.0", P + "transition1.0.1", 1, 0, nullptr, nullptr, R));
-    ys.push_back(B.conv(x, P + "transition1.1.0.0", P + "transition1.1.0.1", 2, 0, nullptr, nullptr, R));
+    std::vector<TView> ys(2);
+    B.fork_join(Op::FORK, 1);                               // the two transition convolutions read the same tensor: side by side where branch streams are on
+    B.set_stream(1);
+    ys[1] = B.conv(x, P + "transition1.1.0.0", P + "transition1.1.0.1", 2, 0, nullptr, nullptr, R);
+    B.set_stream(0);
+    ys[0] = B.conv(x, P + "transition1.0.0", P + "transition1.0.1", 1, 0, nullptr, nullptr, R);
+    B.fork_join(Op::JOIN, 1);
     B.release(x);
     ys = hr_stage(B, ys, 2, 1, 2, false);
     ys.push_back(B.conv(ys.back(), P + "transition2.2.0.0", P + "transition2.2.0.1", 2, 0, nullptr, nullptr, R));

@@ -14,7 +14,7 @@ def run():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     import time
     from eagle_amd import lib, synth, weights
-    h = lib.Handle(batch=1)
+    h = lib.Handle(batch=1, **({"use_graph": 0} if "nograph" in sys.argv else {}))
     weights.load_into(h, [weights.make_hrnet_state_dict(0), weights.make_yolo_state_dict("n", 0)])
     clip = synth.clip(seed=0, n=4)
     out = np.zeros(1, lib.RESULT_DTYPE)
@@ -69,3 +69,18 @@ def parse(d):
 
 if __name__ == "__main__":
     run() if sys.argv[1] == "run" else parse(sys.argv[2])
+    if sys.argv[1] == "parse" and "--timeline" in sys.argv:      # the last call's kernels between two offsets (us): --timeline A B
+        a0, a1 = float(sys.argv[sys.argv.index("--timeline") + 1]), float(sys.argv[sys.argv.index("--timeline") + 2])
+        f = sorted(glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True))[-1]
+        ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in csv.DictReader(open(f)))
+        calls, cur = [], [ev[0]]
+        for e in ev[1:]:
+            if e[0] - max(x[1] for x in cur[-8:]) > 150_000:
+                calls.append(cur); cur = []
+            cur.append(e)
+        calls.append(cur)
+        c = [c for c in calls if len(c) > 100][-1]
+        for s_, e_, n_, q_ in c:
+            a = (s_ - c[0][0]) / 1e3
+            if a0 <= a <= a1:
+                print(f"{a:8.1f} {(e_ - s_) / 1e3:7.1f}  q{q_}  {n_.replace('void eagle::', '').replace('eagle::', '').split('(')[0][:50]}")

@@ -1338,11 +1338,15 @@ int eagle_resolve_config(EagleConfig* cfg)
     // the network phase is replayed as ONE hipGraph and HRNet's branches (and the detector) run on their own streams so that the small launches of
     // different branches fill the CUs together.  Measured on MI355X (default handle, per call incl. H2D and records back, bench.py `latency`): B = 1
     // 13.9 -> 9.6 ms, B = 4 252 -> 344 frames/s, B = 8 395 -> 505 frames/s; at B = 50 the same switches measure nothing (DESIGN.md §4b xii), so larger
-    // batches keep one stream per network and plain launches.  EAGLE_MULTI_STREAM in the environment forces the branch streams on for any batch.
+    // batches keep plain launches (no graph replay).
     // Sweep on one box (profiles/r05c_latency_modes.txt; frames/s plain -> small-batch mode): B = 1 72 -> 105, 4 252 -> 344, 8 395 -> 505, 12 506 -> 571,
     // 16 530 -> 599 (the branch streams alone; the graph adds nothing beyond B = 8), 25 658 -> 674 (graph replay of a 25-frame step: 455, it loses), 50 0.
     if (cfg->use_graph == EAGLE_AUTO) cfg->use_graph = (cfg->batch >= 1 && cfg->batch <= EAGLE_SMALL_BATCH) ? 1 : 0;      // (2 = replay only inside calls of >= 3 steps: on request)
-    if (cfg->multi_stream == EAGLE_AUTO) cfg->multi_stream = ((cfg->batch >= 1 && cfg->batch <= EAGLE_MULTI_STREAM_BATCH) || getenv("EAGLE_MULTI_STREAM") != nullptr) ? 1 : 0;
+    // Branch streams: on for EVERY batch since round 6.  Until then they paid up to 16 frames per step and measured nothing at 50; with the fuse outputs on parallel
+    // streams and the branches' blocks interleaved (hr_stage) the small launches of a module's fuse phase and the tails of its branch launches overlap at any
+    // batch: B = 50, same box, three alternating pairs 810.2 / 806.4 / 805.7 -> 823.1 / 820.2 / 818.0 frames/s (profiles/r06aj_*).  EAGLE_MULTI_STREAM=0 in the
+    // environment resolves "auto" to one stream per network (developer A/B).
+    if (cfg->multi_stream == EAGLE_AUTO) cfg->multi_stream = (getenv("EAGLE_MULTI_STREAM") && atoi(getenv("EAGLE_MULTI_STREAM")) == 0) ? 0 : 1;
     return EAGLE_OK;
 }
 

@@ -45,7 +45,7 @@ extern "C" {
 
 #define EAGLE_AUTO (-1)          /* EagleConfig::use_graph / multi_stream: chosen from `batch` by eagle_create (eagle_resolve_config) */
 #define EAGLE_SMALL_BATCH 8      /* steps of at most this many frames replay their network phase as a hipGraph unless the caller says otherwise */
-#define EAGLE_MULTI_STREAM_BATCH 16 /* ... and steps of at most this many run HRNet's branches on their own streams (measured: +13 % at 12 and 16 frames, +2 % at 25, nothing at 50) */
+/* (EAGLE_MULTI_STREAM_BATCH, rounds 5 - 6a: branch streams only up to 16 frames per step.  Since the fuse outputs run on parallel streams they pay at every batch: "auto" = on) */
 #define EAGLE_DET_PREC_AUTO (-1) /* EagleConfig::det_precision: chosen from `precision` by eagle_create */
 #define EAGLE_DET_PREC_MIXED 4   /* EagleConfig::det_precision: the detector's trunk in EAGLE_PREC_F32S; the last C2f of every level (model.15 / 18 / 21), model.16 / 19 and
                                     Detect in EAGLE_PREC_F32.  Measured and NOT the default: it does not keep the exact family's detection ids */
@@ -87,9 +87,9 @@ typedef struct EagleConfig {
                                   that takes the defaults and only sets precision = EAGLE_PREC_F16 gets BOTH networks in the fast family) */
     int32_t allow_saturation;  /* EAGLE_PREC_F32S: 0 (default): a call in which an activation store was clipped at +-4094 returns EAGLE_E_RANGE;
                                   1: it returns EAGLE_OK and only flags the frames (EagleFrameResult.pad[1]) and counts them (EagleTimings) */
-    int32_t multi_stream;      /* 1: HRNet's branches on their own HIP streams inside a step; 0: one stream per network; EAGLE_AUTO (default): 1 when
-                                  batch <= EAGLE_MULTI_STREAM_BATCH or EAGLE_MULTI_STREAM is set in the environment (at large batches every launch fills the
-                                  chip and the extra streams measure nothing) */
+    int32_t multi_stream;      /* 1: HRNet's branches — and, behind their join, the outputs of its fuse layers — on their own HIP streams inside a step;
+                                  0: one stream per network; EAGLE_AUTO (default): 1 (every batch since round 6: +13 % at 12 - 16 frames per step, +1.6 %
+                                  at 50; EAGLE_MULTI_STREAM=0 in the environment resolves "auto" to 0) */
     int32_t letterbox;         /* detector input geometry (ultralytics LetterBox): EAGLE_LETTERBOX_RECT (0, default) = auto=True, what the .pt predictor
                                   of cm.py:56-57 does — pad only to the next multiple of 32 (1280x720 @640 -> 384 x 640, 5040 anchors);
                                   EAGLE_LETTERBOX_SQUARE (1) = auto=False, what the exported ONNX detector of the reference's CPU default runs with (cm.py:54-55,

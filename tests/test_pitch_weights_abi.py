@@ -108,7 +108,7 @@ def test_default_config_semantics_and_new_fields():
     # small-batch mode (round 5): use_graph / multi_stream default to "auto" and resolve from the batch
     assert (c.use_graph, c.multi_stream) == (lib.AUTO, lib.AUTO)
     os.environ.pop("EAGLE_MULTI_STREAM", None)
-    for B, want in ((1, (1, 1)), (lib.SMALL_BATCH, (1, 1)), (lib.SMALL_BATCH + 1, (0, 1)), (lib.MULTI_STREAM_BATCH, (0, 1)), (lib.MULTI_STREAM_BATCH + 1, (0, 0)), (50, (0, 0))):
+    for B, want in ((1, (1, 1)), (lib.SMALL_BATCH, (1, 1)), (lib.SMALL_BATCH + 1, (0, 1)), (16, (0, 1)), (17, (0, 1)), (50, (0, 1))):      # (round 6: branch streams at every batch)
         r = lib.resolve_config(lib.default_config(batch=B))
         assert (r.use_graph, r.multi_stream) == want, B
     r = lib.resolve_config(lib.default_config(batch=1, use_graph=0, multi_stream=0))

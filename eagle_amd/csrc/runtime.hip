@@ -488,8 +488,8 @@ static std::vector<TView> hr_stage(Builder& B, std::vector<TView> xs, int stage_
         const int n_out = (last_single && m == n_modules - 1) ? 1 : nb;
         std::vector<TView> out;
         // (round 6) The fuse outputs are independent of each other: output i — its chain of stride-2 convolutions from the higher-resolution branches, its 1 x 1
-        // convolutions of the lower ones, its fuse_sum — is emitted for stream i, so that with branch streams on (small batches) the module's 19 fuse launches are
-        // four parallel chains of at most 6 instead of one serial chain behind the join: 0.85 ms of a one-frame call (7.5 -> 6.66 ms, profiles/r06ad_*).  The inputs
+        // convolutions of the lower ones, its fuse_sum — is emitted for stream i, so that with branch streams on (every batch since this round) the module's 19 fuse launches are
+        // four parallel chains of at most 6 instead of one serial chain behind the join: 7.5 -> 6.66 ms per one-frame call, +1.6 .. 2.8 % at B = 50 (r06aj, r06ak).  The inputs
         // xs[] are only read; everything a chain allocates and releases stays in its own stream's pool.  Same launches, same arithmetic.  (Measured and not kept: also
         // moving the launches that need only ONE branch's output in front of the join, behind that branch — nothing, twice: profiles/r06ai_*.)
         if (n_out > 1) B.fork_join(Op::FORK, n_out - 1);

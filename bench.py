@@ -397,7 +397,7 @@ def main():
     latency = None
     if extras and a.latency_calls > 0:
         # small-batch behaviour (north_star's API is Processor.process(frame); the reference's loop hands over one frame per iteration, cm.py:277):
-        # per-call wall time of eagle_process_frames at B = 1, 2, 4, 8 on the default handle (small-batch mode = the library's default for batch <= 8:
+        # per-call wall time of eagle_process_frames at B = 1, 2, 4, 8 on the default handle (small-batch mode = the library's default for batch <= EAGLE_SMALL_BATCH:
         # hipGraph replay + HRNet's branches on their own streams), and the same handle with both switched off
         fr = clip[:max(16, min(len(base), 64))]
         latency = {"unit": "ms per eagle_process_frames call of B frames from pageable host memory (records back on the host)",

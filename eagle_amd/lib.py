@@ -14,7 +14,7 @@ MAX_DET, N_LANDMARKS, MAX_KP = 300, 57, 87
 PREC_F16, PREC_F32, PREC_F32S = 0, 1, 2
 PRECISIONS = {"f16": PREC_F16, "f32": PREC_F32, "f32s": PREC_F32S}      # include/eagle.h EAGLE_PREC_*
 DET_VARIANTS = {"n": 0, "s": 1, "m": 2, "l": 3, "x": 4}
-AUTO, SMALL_BATCH = -1, 8                                              # include/eagle.h EAGLE_AUTO / EAGLE_SMALL_BATCH (use_graph: 0 off, 1 every step, 2 inside calls of >= 3 steps; multi_stream)
+AUTO, SMALL_BATCH = -1, 32                                             # include/eagle.h EAGLE_AUTO / EAGLE_SMALL_BATCH (use_graph: 0 off, 1 every step, 2 inside calls of >= 3 steps; multi_stream)
 LETTERBOX = {"rect": 0, "square": 1}                                    # include/eagle.h EAGLE_LETTERBOX_*: ultralytics LetterBox auto=True (the .pt predictor) / auto=False (the exported ONNX detector of cm.py:54-55)
 DET_PREC_AUTO = -1                                                     # include/eagle.h EAGLE_DET_PREC_AUTO
 DET_PREC_MIXED = 4                                                     # include/eagle.h EAGLE_DET_PREC_MIXED (split trunk, exact last C2f per level + Detect)

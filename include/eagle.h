@@ -44,7 +44,8 @@ extern "C" {
                                   another order, at 3/16 of the fp32 MFMA's cost per product */
 
 #define EAGLE_AUTO (-1)          /* EagleConfig::use_graph / multi_stream: chosen from `batch` by eagle_create (eagle_resolve_config) */
-#define EAGLE_SMALL_BATCH 8      /* steps of at most this many frames replay their network phase as a hipGraph unless the caller says otherwise */
+#define EAGLE_SMALL_BATCH 32     /* steps of at most this many frames replay their network phase as a hipGraph unless the caller says otherwise (8 until the middle of round 6:
+                                    with the branch streams' schedule the replay now pays in one-step calls up to 50 frames, +11 % at 8, +5 % at 16, +3 % at 25, +2 % at 32) */
 /* (EAGLE_MULTI_STREAM_BATCH, rounds 5 - 6a: branch streams only up to 16 frames per step.  Since the fuse outputs run on parallel streams they pay at every batch: "auto" = on) */
 #define EAGLE_DET_PREC_AUTO (-1) /* EagleConfig::det_precision: chosen from `precision` by eagle_create */
 #define EAGLE_DET_PREC_MIXED 4   /* EagleConfig::det_precision: the detector's trunk in EAGLE_PREC_F32S; the last C2f of every level (model.15 / 18 / 21), model.16 / 19 and

@@ -795,17 +795,17 @@ def test_small_batch_mode_records_equal_the_large_batch_handles(state_dicts, fra
     from eagle_amd import lib
     from eagle_amd.coordinate_model import CoordinateModel
     hs, ys = state_dicts
-    big = CoordinateModel(batch=17, hrnet_state_dict=hs, detector_state_dict=ys, multi_stream=False)        # plain launches, one stream per network
+    big = CoordinateModel(batch=17, hrnet_state_dict=hs, detector_state_dict=ys, use_graph=False, multi_stream=False)        # plain launches, one stream per network
     assert (big.handle.cfg.use_graph, big.handle.cfg.multi_stream) == (0, 0)
     ref = big.process_records(frames)
     big.handle.close()
-    dflt = CoordinateModel(batch=17, hrnet_state_dict=hs, detector_state_dict=ys)                           # round 6: branch streams are the default at every batch
-    assert (dflt.handle.cfg.use_graph, dflt.handle.cfg.multi_stream) == (0, 1)
+    dflt = CoordinateModel(batch=17, hrnet_state_dict=hs, detector_state_dict=ys)                           # round 6: branch streams at every batch, graph replay up to 32 frames per step
+    assert (dflt.handle.cfg.use_graph, dflt.handle.cfg.multi_stream) == (1, 1)
     assert dflt.process_records(frames).tobytes() == ref.tobytes()
     dflt.handle.close()
     for B in (1, 2, 4, 8, 12):
         m = CoordinateModel(batch=B, hrnet_state_dict=hs, detector_state_dict=ys)
-        assert (m.handle.cfg.use_graph, m.handle.cfg.multi_stream) == ((1, 1) if B <= 8 else (0, 1)), B
+        assert (m.handle.cfg.use_graph, m.handle.cfg.multi_stream) == (1, 1), B       # (EAGLE_SMALL_BATCH = 32 since round 6)
         got = m.process_records(frames)                     # 5 frames: ragged last step at B = 2, 4, 8 (another graph instance)
         again = m.process_records(frames[:1])               # a second call with another frame count on the same handle
         m.handle.close()

@@ -108,12 +108,12 @@ def test_default_config_semantics_and_new_fields():
     # small-batch mode (round 5): use_graph / multi_stream default to "auto" and resolve from the batch
     assert (c.use_graph, c.multi_stream) == (lib.AUTO, lib.AUTO)
     os.environ.pop("EAGLE_MULTI_STREAM", None)
-    for B, want in ((1, (1, 1)), (lib.SMALL_BATCH, (1, 1)), (lib.SMALL_BATCH + 1, (0, 1)), (16, (0, 1)), (17, (0, 1)), (50, (0, 1))):      # (round 6: branch streams at every batch)
+    for B, want in ((1, (1, 1)), (lib.SMALL_BATCH, (1, 1)), (16, (1, 1)), (lib.SMALL_BATCH + 1, (0, 1)), (50, (0, 1))):      # (round 6: branch streams at every batch)
         r = lib.resolve_config(lib.default_config(batch=B))
         assert (r.use_graph, r.multi_stream) == want, B
     r = lib.resolve_config(lib.default_config(batch=1, use_graph=0, multi_stream=0))
     assert (r.use_graph, r.multi_stream) == (0, 0)
-    assert "EAGLE_SMALL_BATCH 8" in open(os.path.join(ROOT, "include", "eagle.h")).read()
+    assert "EAGLE_SMALL_BATCH %d " % lib.SMALL_BATCH in open(os.path.join(ROOT, "include", "eagle.h")).read()
     assert lib.default_config(allow_saturation=1).allow_saturation == 1
     assert issubclass(lib.EagleRangeError, lib.EagleError) and lib.E_RANGE == -8
     hdr = open(os.path.join(ROOT, "include", "eagle.h")).read()
